@@ -1,0 +1,227 @@
+"""ctypes binding of the CPU oracle (oracle/liby2oracle.so).  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module; nothing under sr_object_detection_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liby2oracle.so")
+REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+
+KINDS = ["convolutional", "maxpool", "route", "reorg", "region", "avgpool", "softmax", "cost"]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "y2_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "liby2oracle.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_parse_cfg.restype = C.c_void_p
+        L.orc_parse_cfg.argtypes = [C.c_char_p]
+        L.orc_free_net.argtypes = [C.c_void_p]
+        L.orc_load_weights.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_predict.restype = fp
+        L.orc_predict.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_num_layers.argtypes = [C.c_void_p]
+        L.orc_batch.argtypes = [C.c_void_p]
+        L.orc_inputs.argtypes = [C.c_void_p]
+        L.orc_last_layer.argtypes = [C.c_void_p]
+        L.orc_layer_output.restype = fp
+        L.orc_layer_output.argtypes = [C.c_void_p, C.c_int]
+        L.orc_layer_param.restype = fp
+        L.orc_layer_param.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_layer_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_net_dims.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_region_boxes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_do_nms_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.orc_do_nms.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        L.orc_box_iou.restype = C.c_float
+        L.orc_box_iou.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_detector_bboxes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_int]
+        L.orc_test_detector_objects.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int]
+        L.orc_maxpool.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_reorg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_flatten.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_softmax.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.orc_top_k.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_resize_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_time_predict.restype = C.c_double
+        L.orc_time_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleNet:
+    """The oracle's network: parse a cfg, load weights, predict, decode, NMS."""
+
+    def __init__(self, cfg_path: str, weights_path: str | None = None):
+        self.L = lib()
+        self.h = self.L.orc_parse_cfg(cfg_path.encode())
+        if not self.h:
+            raise RuntimeError("oracle: cfg parse failed: %s" % cfg_path)
+        if weights_path:
+            if self.L.orc_load_weights(self.h, weights_path.encode()) != 0:
+                raise RuntimeError("oracle: weights load failed: %s" % weights_path)
+        dims = (C.c_int * 4)()
+        self.L.orc_net_dims(self.h, dims)
+        self.w, self.hgt, self.c, self.batch = list(dims)
+        self.n = self.L.orc_num_layers(self.h)
+        self.inputs = self.L.orc_inputs(self.h)
+        self.last = self.L.orc_last_layer(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.orc_free_net(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def layer_info(self, i: int) -> dict:
+        info = (C.c_int * 16)()
+        self.L.orc_layer_info(self.h, i, info)
+        keys = ["kind", "w", "h", "c", "out_w", "out_h", "out_c", "outputs", "n", "size", "stride", "pad",
+                "batch_normalize", "activation", "classes", "coords"]
+        d = dict(zip(keys, list(info)))
+        d["type"] = KINDS[d["kind"]]
+        return d
+
+    def layer_output(self, i: int) -> np.ndarray:
+        info = self.layer_info(i)
+        n = info["outputs"] * self.batch
+        ptr = self.L.orc_layer_output(self.h, i)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+    def predict(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        assert x.size == self.inputs * self.batch, (x.size, self.inputs, self.batch)
+        ptr = self.L.orc_predict(self.h, _p(x))
+        n = self.layer_info(self.last)["outputs"] * self.batch
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+    def region_boxes(self, b: int, thresh: float, w: int = 1, h: int = 1, only_objectness: int = 0, use_map: int = 0):
+        info = self.layer_info(self.last)
+        assert info["type"] == "region"
+        total = info["w"] * info["h"] * info["n"]
+        probs = np.zeros((total, info["classes"]), dtype=np.float32)
+        boxes = np.zeros((total, 4), dtype=np.float32)
+        self.L.orc_get_region_boxes(self.h, self.last, b, w, h, thresh, _p(probs), _p(boxes), only_objectness, use_map)
+        return boxes, probs
+
+    def time_predict(self, x: np.ndarray, iters: int) -> float:
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        return float(self.L.orc_time_predict(self.h, _p(x), iters))
+
+
+def do_nms_sort(boxes: np.ndarray, probs: np.ndarray, thresh: float) -> np.ndarray:
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    probs = np.array(probs, dtype=np.float32, order="C", copy=True)
+    lib().orc_do_nms_sort(_p(boxes), _p(probs), probs.shape[0], probs.shape[1], thresh)
+    return probs
+
+
+def do_nms(boxes: np.ndarray, probs: np.ndarray, thresh: float) -> np.ndarray:
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    probs = np.array(probs, dtype=np.float32, order="C", copy=True)
+    lib().orc_do_nms(_p(boxes), _p(probs), probs.shape[0], probs.shape[1], thresh)
+    return probs
+
+
+def box_iou(a, b) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return float(lib().orc_box_iou(_p(a), _p(b)))
+
+
+def detector_bboxes(boxes, probs, thresh: float, im_w: int, im_h: int) -> np.ndarray:
+    """-> structured array of bbox_t (x,y,w,h,prob,obj_id,track_id) (yolo_v2_class.hpp:27)."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    total, classes = probs.shape
+    out = np.zeros((total, 7), dtype=np.uint32)
+    n = lib().orc_detector_bboxes(_p(boxes), _p(probs), total, classes, thresh, im_w, im_h, _p(out), total)
+    dt = np.dtype([("x", "<u4"), ("y", "<u4"), ("w", "<u4"), ("h", "<u4"), ("prob", "<f4"), ("obj_id", "<u4"), ("track_id", "<u4")])
+    return out[:n].copy().view(dt).reshape(-1)
+
+
+def test_detector_objects(boxes, probs, thresh: float) -> np.ndarray:
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    total, classes = probs.shape
+    out = np.zeros((total, 9), dtype=np.float32)
+    n = lib().orc_test_detector_objects(_p(boxes), _p(probs), total, classes, thresh, _p(out), total)
+    return out[:n].copy()
+
+
+test_detector_objects.__test__ = False  # not a pytest test
+
+
+def maxpool(x, batch, h, w, c, size, stride, pad):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    oh, ow = (h + 2 * pad) // stride, (w + 2 * pad) // stride
+    out = np.zeros(batch * c * oh * ow, dtype=np.float32)
+    lib().orc_maxpool(_p(x), batch, h, w, c, size, stride, pad, _p(out))
+    return out
+
+
+def reorg(x, w, h, c, batch, stride, forward=0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros_like(x)
+    lib().orc_reorg(_p(x), w, h, c, batch, stride, forward, _p(out))
+    return out
+
+
+def flatten(x, size, layers, batch, forward=1):
+    x = np.array(x, dtype=np.float32, order="C", copy=True)
+    lib().orc_flatten(_p(x), size, layers, batch, forward)
+    return x
+
+
+def softmax(x, temp=1.0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros_like(x)
+    lib().orc_softmax(_p(x), x.size, temp, _p(out))
+    return out
+
+
+def top_k(a, k):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    idx = np.zeros(k, dtype=np.int32)
+    lib().orc_top_k(_p(a), a.size, k, _p(idx))
+    return idx
+
+
+def resize_image(im: np.ndarray, w: int, h: int) -> np.ndarray:
+    """im: [c][ih][iw] float32 -> [c][h][w] (src_yolo2/image.c:1950)."""
+    im = np.ascontiguousarray(im, dtype=np.float32)
+    c, ih, iw = im.shape
+    out = np.zeros((c, h, w), dtype=np.float32)
+    lib().orc_resize_image(_p(im), iw, ih, c, w, h, _p(out))
+    return out

@@ -1,0 +1,162 @@
+"""Network definitions for the BASELINE.json configurations, as Darknet cfg text.
+
+The engine parses ordinary Darknet .cfg files (the grammar of
+src_yolo2/parser.c:702-735).  The reference's cfg/*.cfg files do not travel to
+the GPU box, so the benchmark/test networks are emitted here from compact
+specs; tests/test_cfg_equivalence.py checks, when /root/reference is present,
+that each emitted text parses to the same layer table as the reference's own
+cfg file (cfg/yolo.cfg, cfg/tiny-yolo-voc.cfg, cfg/yolo9000.cfg,
+cfg/darknet19_448.cfg).
+
+`resolve()` is a small shape-inference pass over a spec (the rules of
+parser.c:139-170, :359-374, :343-357, :450-489, :236-285) used only to size
+synthetic weights and to report FLOPs; the engine does its own parse in C.
+"""
+from __future__ import annotations
+
+# spec entries:
+#   ("conv", filters, size, bn, activation)      stride 1, pad=1
+#   ("max", size, stride) | ("route", [idx...]) | ("reorg", stride)
+#   ("region", dict) | ("avg",) | ("softmax",) | ("cost",)
+
+_D19_TRUNK = [
+    ("conv", 32, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 64, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 128, 3, 1, "leaky"), ("conv", 64, 1, 1, "leaky"), ("conv", 128, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 256, 3, 1, "leaky"), ("conv", 128, 1, 1, "leaky"), ("conv", 256, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 512, 3, 1, "leaky"), ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"),
+    ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 1024, 3, 1, "leaky"), ("conv", 512, 1, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"),
+    ("conv", 512, 1, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"),
+]
+
+COCO_ANCHORS = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
+VOC_TINY_ANCHORS = [1.08, 1.19, 3.42, 4.41, 6.63, 11.38, 9.42, 5.11, 16.62, 10.52]
+Y9K_ANCHORS = [0.77871, 1.14074, 3.00525, 4.31277, 9.22725, 9.61974]
+
+SPECS = {
+    # cfg/yolo.cfg (YOLOv2-COCO): Darknet-19 trunk + passthrough (route/reorg) head
+    "yolo": _D19_TRUNK + [
+        ("conv", 1024, 3, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"),
+        ("route", [-9]), ("conv", 64, 1, 1, "leaky"), ("reorg", 2), ("route", [-1, -4]),
+        ("conv", 1024, 3, 1, "leaky"), ("conv", 425, 1, 0, "linear"),
+        ("region", {"classes": 80, "num": 5, "anchors": COCO_ANCHORS}),
+    ],
+    # cfg/tiny-yolo-voc.cfg
+    "tiny-yolo-voc": [
+        ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("conv", 32, 3, 1, "leaky"), ("max", 2, 2),
+        ("conv", 64, 3, 1, "leaky"), ("max", 2, 2), ("conv", 128, 3, 1, "leaky"), ("max", 2, 2),
+        ("conv", 256, 3, 1, "leaky"), ("max", 2, 2), ("conv", 512, 3, 1, "leaky"), ("max", 2, 1),
+        ("conv", 1024, 3, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"), ("conv", 125, 1, 0, "linear"),
+        ("region", {"classes": 20, "num": 5, "anchors": VOC_TINY_ANCHORS}),
+    ],
+    # cfg/yolo9000.cfg: trunk + one 1x1 conv with 3*(9418+5) filters, tree softmax head
+    "yolo9000": _D19_TRUNK + [
+        ("conv", 28269, 1, 0, "linear"),
+        ("region", {"classes": 9418, "num": 3, "anchors": Y9K_ANCHORS, "tree": True, "map": True}),
+    ],
+    # cfg/darknet19_448.cfg classifier
+    "darknet19": _D19_TRUNK + [("conv", 1000, 1, 0, "linear"), ("avg",), ("softmax",), ("cost",)],
+    # small all-layer-types net for fast tests (not a reference cfg): 3x3 + 1x1 convs, 2/2 and 2/1 maxpools,
+    # single- and multi-input routes, reorg, linear head, region
+    "mini": [
+        ("conv", 8, 3, 1, "leaky"), ("max", 2, 2), ("conv", 16, 3, 1, "leaky"), ("conv", 8, 1, 1, "leaky"),
+        ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("conv", 32, 3, 1, "leaky"), ("max", 2, 1),
+        ("conv", 32, 3, 1, "leaky"), ("route", [-5]), ("conv", 4, 1, 1, "leaky"), ("reorg", 2),
+        ("route", [-1, -4]), ("conv", 32, 3, 1, "leaky"), ("conv", 30, 1, 0, "linear"),
+        ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]}),
+    ],
+}
+
+DEFAULT_SIZE = {"yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32}
+
+
+def cfg_text(name: str, width: int | None = None, height: int | None = None, batch: int = 1,
+             tree_path: str | None = None, map_path: str | None = None, spec=None) -> str:
+    """Darknet cfg text for one of SPECS (or an explicit spec list)."""
+    spec = SPECS[name] if spec is None else spec
+    width = width or DEFAULT_SIZE.get(name, 416)
+    height = height or width
+    out = ["[net]", "batch=%d" % batch, "subdivisions=1", "width=%d" % width, "height=%d" % height, "channels=3", ""]
+    for e in spec:
+        kind = e[0]
+        if kind == "conv":
+            _, filters, size, bn, act = e
+            out += ["[convolutional]", "filters=%d" % filters, "size=%d" % size, "stride=1", "pad=1"]
+            if bn:
+                out.append("batch_normalize=1")
+            out += ["activation=%s" % act, ""]
+        elif kind == "max":
+            out += ["[maxpool]", "size=%d" % e[1], "stride=%d" % e[2], ""]
+        elif kind == "route":
+            out += ["[route]", "layers=" + ",".join(str(i) for i in e[1]), ""]
+        elif kind == "reorg":
+            out += ["[reorg]", "stride=%d" % e[1], ""]
+        elif kind == "region":
+            r = e[1]
+            out += ["[region]", "anchors = " + ", ".join(repr(a) for a in r["anchors"]),
+                    "classes=%d" % r["classes"], "coords=4", "num=%d" % r["num"], "softmax=1"]
+            if r.get("tree"):
+                if not tree_path:
+                    raise ValueError("%s needs tree_path" % name)
+                out.append("tree=%s" % tree_path)
+            if r.get("map") and map_path:
+                out.append("map=%s" % map_path)
+            out.append("")
+        elif kind == "avg":
+            out += ["[avgpool]", ""]
+        elif kind == "softmax":
+            out += ["[softmax]", "groups=1", ""]
+        elif kind == "cost":
+            out += ["[cost]", "type=sse", ""]
+        else:
+            raise ValueError(kind)
+    return "\n".join(out)
+
+
+def resolve(name_or_spec, width: int, height: int | None = None, channels: int = 3):
+    """Layer table with shapes: list of dicts (type, w,h,c, out_w,out_h,out_c, outputs, ...)."""
+    spec = SPECS[name_or_spec] if isinstance(name_or_spec, str) else name_or_spec
+    h = height or width
+    w, c = width, channels
+    inputs = w * h * c
+    layers = []
+    for i, e in enumerate(spec):
+        kind = e[0]
+        L = {"w": w, "h": h, "c": c, "inputs": inputs}
+        if kind == "conv":
+            _, filters, size, bn, act = e
+            pad = size // 2
+            L.update(type="convolutional", filters=filters, size=size, stride=1, pad=pad, batch_normalize=bn,
+                     activation=act, out_w=(w + 2 * pad - size) + 1, out_h=(h + 2 * pad - size) + 1, out_c=filters)
+        elif kind == "max":
+            size, stride = e[1], e[2]
+            pad = (size - 1) // 2
+            L.update(type="maxpool", size=size, stride=stride, pad=pad,
+                     out_w=(w + 2 * pad) // stride, out_h=(h + 2 * pad) // stride, out_c=c)
+        elif kind == "route":
+            idx = [j if j >= 0 else i + j for j in e[1]]
+            first = layers[idx[0]]
+            oc = sum(layers[j]["out_c"] for j in idx)
+            L.update(type="route", layers=idx, out_w=first["out_w"], out_h=first["out_h"], out_c=oc)
+        elif kind == "reorg":
+            s = e[1]
+            L.update(type="reorg", stride=s, out_w=w // s, out_h=h // s, out_c=c * s * s)
+        elif kind == "region":
+            r = e[1]
+            L.update(type="region", classes=r["classes"], coords=4, num=r["num"], anchors=r["anchors"],
+                     out_w=0, out_h=0, out_c=0, outputs=w * h * r["num"] * (r["classes"] + 5))
+        elif kind == "avg":
+            L.update(type="avgpool", out_w=1, out_h=1, out_c=c)
+        elif kind in ("softmax", "cost"):
+            L.update(type=kind, out_w=0, out_h=0, out_c=0, outputs=inputs)
+        L.setdefault("outputs", L["out_w"] * L["out_h"] * L["out_c"])
+        layers.append(L)
+        w, h, c, inputs = L["out_w"], L["out_h"], L["out_c"], L["outputs"]
+    return layers
+
+
+def conv_flops(layers) -> float:
+    """The reference's own FLOP count, 2*M*N*K summed over convs (src_yolo2/darknet.c:115-131)."""
+    return float(sum(2.0 * l["filters"] * l["size"] ** 2 * l["c"] * l["out_h"] * l["out_w"]
+                     for l in layers if l["type"] == "convolutional"))
