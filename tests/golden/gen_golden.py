@@ -43,8 +43,8 @@ CASES = [
     ("yolo_416_b1", "yolo", 416, 1, 31, 0.2, 0.4, 4.0),
     ("yolo_608_b1", "yolo", 608, 1, 31, 0.2, 0.4, 4.0),
     ("darknet19_224_b1", "darknet19", 224, 1, 41, 0.0, 0.0, 1.0),
-    ("yolo9000_160_b1", "yolo9000", 160, 1, 51, 0.2, 0.4, 4.0),
-    ("yolo9000_160_b1_map", "yolo9000", 160, 1, 51, 0.2, 0.4, 4.0),
+    ("yolo9000_96_b1", "yolo9000", 96, 1, 51, 0.2, 0.4, 4.0),
+    ("yolo9000_96_b1_map", "yolo9000", 96, 1, 51, 0.2, 0.4, 4.0),
 ]
 
 
@@ -140,6 +140,9 @@ def generate_case(name, net, size, batch, seed, thresh, nms, gain, use_map):
                 "out": out,
                 "input_checksum": np.float64(x.astype(np.float64).sum()),
             }
+            if use_map:                        # same forward tensor as the non-map case: keep the fixture small
+                fix["out"] = out[:0]
+                fix["out_sum"] = np.float64(out.astype(np.float64).sum())
             if meta["last_type"] == 21:       # REGION in the reference's LAYER_TYPE enum (layer.h:33)
                 total = meta["lw"] * meta["lh"] * meta["ln"]
                 ncls = meta["classes"]
