@@ -1,0 +1,6 @@
+/* Source-compatibility shim: callers of the reference include "region_layer.h"
+ * (src_yolo2/region_layer.h); every declaration now lives in sr_yolo2.h. */
+#ifndef SR_YOLO2_SHIM_REGION_LAYER_H
+#define SR_YOLO2_SHIM_REGION_LAYER_H
+#include "sr_yolo2.h"
+#endif

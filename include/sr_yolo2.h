@@ -1,0 +1,264 @@
+/*
+ * sr_yolo2.h -- drop-in C API of the MI355X-native YOLOv2 / Darknet forward engine.
+ *
+ * This header declares, with the reference's own names, argument meaning and
+ * error behaviour, the entry points a caller of the reference's forward path
+ * binds.  Each declaration cites the reference
+ * interface it replaces (paths relative to src_yolo2/ of
+ * NidhiMishra/SR_object_detection).  The thin headers network.h, parser.h,
+ * layer.h, box.h, region_layer.h, cuda.h, image.h, utils.h, option_list.h,
+ * tree.h and test_detector.h next to this file simply include it, so the
+ * Kinect / CLI callers keep their #include lines.
+ *
+ * Differences a caller can observe (all deliberate):
+ *   - `layer` and `network` keep every field the forward-path callers read
+ *     (yolo_v2_class.cpp:64-76,202-216; KinectUtil.cpp:85; detector.c:568-576)
+ *     but drop the training-only members, and their layout no longer depends
+ *     on -DGPU / -DCUDNN (layer.h:205-263, network.h:63-66): device state
+ *     hangs off one opaque pointer.
+ *   - there is no CPU compute path in this library: network_predict always
+ *     runs on the GPU selected by net.gpu_index (>= 0).  gpu_index < 0, which
+ *     selects the CPU path in the reference (network.c:461), is an error here.
+ *   - only the last non-[cost] layer has a host `output` buffer; other layers'
+ *     activations stay in HBM (use y2_pull_layer_output to inspect them).
+ *   - set_batch_network may grow the batch (the reference overflows its
+ *     parse-time buffers); buffers are re-planned lazily.
+ *   - net.seen is 8 bytes, so a version >= 0.2 .weights header no longer
+ *     overruns it (parser.c:1027-1029 vs network.c:137).
+ */
+#ifndef SR_YOLO2_H
+#define SR_YOLO2_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums: names and order are part of the ABI callers compile against ---- */
+/* activations.h:7-9 */
+typedef enum {
+    LOGISTIC, RELU, RELIE, LINEAR, RAMP, TANH, PLSE, LEAKY, ELU, LOGGY, STAIR, HARDTAN, LHTAN
+} ACTIVATION;
+
+/* layer.h:13-38 */
+typedef enum {
+    CONVOLUTIONAL, DECONVOLUTIONAL, CONNECTED, MAXPOOL, SOFTMAX, DETECTION, DROPOUT, CROP, ROUTE, COST,
+    NORMALIZATION, AVGPOOL, LOCAL, SHORTCUT, ACTIVE, RNN, GRU, CRNN, BATCHNORM, NETWORK, XNOR, REGION, REORG, BLANK
+} LAYER_TYPE;
+
+/* layer.h:40-42 */
+typedef enum { SSE, MASKED, SMOOTH } COST_TYPE;
+
+/* tree.h:4-14 */
+typedef struct {
+    int *leaf;
+    int n;
+    int *parent;
+    int *group;
+    char **name;
+    int groups;
+    int *group_size;
+    int *group_offset;
+} tree;
+
+/* box.h:4-6 */
+typedef struct { float x, y, w, h; } box;
+
+/* image.h:12-17: CHW planes, values in [0,1] */
+typedef struct { int h; int w; int c; float *data; } image;
+
+/* utils.h:14-28: what test_detector_img hands to the Kinect pipeline */
+typedef struct {
+    float x, y;
+    float w, h;
+    char name[20];
+    float prob;
+    int objClass;
+    float CameraX, CameraY, CameraZ;
+    float CameraWidth, CameraHeight;
+    unsigned char flagBelong2Person;
+    float boxRGB[3];
+    int bodyId;
+} object;
+
+/* list.h / option_list.h: key=value lists returned by read_data_cfg */
+typedef struct node { void *val; struct node *next; struct node *prev; } node;
+typedef struct list { int size; node *front; node *back; } list;
+typedef struct { char *key; char *val; int used; } kvp;
+
+struct layer;
+typedef struct layer layer;
+struct network;
+
+/* layer.h:44-264, forward-path subset.  Host-visible description of one layer. */
+struct layer {
+    LAYER_TYPE type;
+    ACTIVATION activation;
+    COST_TYPE cost_type;
+    int batch_normalize;
+    int batch;
+    int flipped;
+    int inputs, outputs;
+    int h, w, c;
+    int out_h, out_w, out_c;
+    int n;                     /* filters | anchors | number of route inputs */
+    int groups;
+    int size, stride, pad;
+    int reverse;
+    int index;
+    int binary, xnor;
+    /* [region] */
+    int softmax, classes, coords, classfix, log, sqrt, max_boxes, rescore, bias_match, random, absolute, truths;
+    float jitter, thresh, coord_scale, object_scale, noobject_scale, class_scale;
+    /* [softmax] / [cost] */
+    float temperature, scale;
+    int dontload, dontloadscales;
+    tree *softmax_tree;
+    int *map;
+    int *input_layers, *input_sizes;      /* [route] */
+    float *biases, *scales, *weights;     /* host copies, reference layouts ([n][c][k][k]) */
+    float *rolling_mean, *rolling_variance;
+    float *output;                        /* host; non-NULL only for the network's output layer */
+    float *delta;                         /* always NULL (no training) */
+    float *cost;
+    size_t workspace_size;                /* the reference's im2col bytes (convolutional_layer.c:135); informational */
+    void *dev;                            /* opaque device-side state */
+};
+
+/* network.h:19-67, forward-path subset */
+typedef struct network {
+    float *workspace;          /* always NULL: there is no im2col workspace */
+    int n;
+    int batch;
+    int *seen;                 /* 8 bytes are allocated behind this pointer */
+    int subdivisions;
+    float learning_rate, momentum, decay;
+    int max_batches, time_steps;
+    layer *layers;
+    int outputs;
+    float *output;
+    int inputs;
+    int h, w, c;
+    int gpu_index;
+    tree *hierarchy;
+    void *engine;              /* opaque: plan, HBM buffers, stream */
+} network;
+
+/* network.h:69-77 kept for source compatibility of callers that mention the type */
+typedef struct network_state {
+    float *truth;
+    float *input;
+    float *delta;
+    float *workspace;
+    int train;
+    int index;
+    network net;
+} network_state;
+
+/* ---- device selection (cuda.h:8,28; cuda.c:1,12) ---- */
+extern int gpu_index;                          /* default device for parse_network_cfg; 0 at start-up */
+void cuda_set_device(int n);
+
+/* ---- cfg + weights (parser.h:5-11) ---- */
+network parse_network_cfg(char *filename);                       /* parser.c:585 */
+void load_weights(network *net, char *filename);                 /* parser.c:1084 */
+void load_weights_upto(network *net, char *filename, int cutoff);/* parser.c:1009 */
+void save_weights(network net, char *filename);                  /* parser.c:878  (version 0.1 header) */
+void save_weights_upto(network net, char *filename, int cutoff); /* parser.c:822 */
+
+/* ---- network runtime (network.h:83-127) ---- */
+network make_network(int n);                                     /* network.c:132 */
+void free_network(network net);                                  /* network.c:592 */
+void set_batch_network(network *net, int b);                     /* network.c:308 */
+int resize_network(network *net, int w, int h);                  /* network.c:322 */
+float *network_predict(network net, float *input);               /* network.c:458 */
+float *network_predict_gpu(network net, float *input);           /* network_kernels.cu:392 */
+float *get_network_output(network net);                          /* network.c:173 */
+float *get_network_output_gpu(network net);                      /* network_kernels.cu:385 */
+int get_network_output_size(network net);                        /* network.c:390 */
+int get_network_input_size(network net);                         /* network.c:397 */
+void top_predictions(network net, int k, int *index);            /* network.c:449 */
+char *get_layer_string(LAYER_TYPE a);                            /* network.c:73 */
+
+/* ---- region head hand-off (region_layer.h:12, box.h:13-17) ---- */
+void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *boxes, int only_objectness, int *map);
+void do_nms_sort(box *boxes, float **probs, int total, int classes, float thresh);   /* box.c:249 */
+void do_nms(box *boxes, float **probs, int total, int classes, float thresh);        /* box.c:279 */
+float box_iou(box a, box b);                                                         /* box.c:94  */
+box float_to_box(float *f);                                                          /* box.c:5   */
+
+/* ---- Kinect-pipeline entry (test_detector.h:2, detector.c:558) ---- */
+void test_detector_img(char **names, image **alphabet, network net, image im, float thresh,
+                       object *RecObects, int *objectNumPerFrame);
+
+/* ---- small helpers the callers use (option_list.h:12-19, data.c:474, utils.c, tree.c, image.c) ---- */
+list *read_data_cfg(char *filename);
+char *option_find(list *l, char *key);
+char *option_find_str(list *l, char *key, char *def);
+int option_find_int(list *l, char *key, int def);
+int option_find_int_quiet(list *l, char *key, int def);
+float option_find_float(list *l, char *key, float def);
+float option_find_float_quiet(list *l, char *key, float def);
+void free_list(list *l);
+char **get_labels(char *filename);
+image **load_alphabet(void);               /* glyph PNGs are UI (image.c:212): returns NULL here */
+tree *read_tree(char *filename);           /* tree.c:53 */
+int *read_map(char *filename);             /* utils.c:17 */
+int max_index(float *a, int n);            /* utils.c:533 */
+void top_k(float *a, int n, int k, int *index);   /* utils.c:179 */
+void mean_arrays(float **a, int n, int els, float *avg);   /* utils.c:420 */
+image make_image(int w, int h, int c);     /* image.c:1436 */
+void free_image(image m);                  /* image.c:2245 */
+image resize_image(image im, int w, int h);/* image.c:1950; runs on the GPU */
+float get_color(int c, int x, int max);    /* image.c:33 */
+void error(const char *s);                 /* utils.c:195: perror + exit(-1) */
+void file_error(char *s);                  /* utils.c:208: message + exit(0) */
+
+/* ------------------------------------------------------------------------- */
+/* Extensions (not in the reference): batched, HBM-resident operation        */
+/* ------------------------------------------------------------------------- */
+
+/* one detection of y2_detect*: centre-form box scaled by (img_w,img_h) of the call */
+typedef struct { float x, y, w, h, prob; int obj_id; } y2_det;
+
+/* Build plan, allocate HBM and upload weights now instead of at the first predict.  Returns 0 or <0. */
+int y2_prepare(network *net);
+/* Force every convolution through the reference-order VALU kernel (bit-identical to the CPU path). */
+void y2_set_strict(network *net, int strict);
+/* The packed, kernel-layout weight arena (one allocation; what a multi-GPU launcher broadcasts). */
+int y2_weights_arena(network *net, void **dev_ptr, size_t *bytes);
+/* Declare the arena contents valid although load_weights was not called on this process
+ * (e.g. it was filled by an RCCL broadcast from rank 0). */
+void y2_weights_resident(network *net);
+/* network_predict with the input already in HBM (NCHW, batch*inputs floats).  The returned
+ * pointer is the same host buffer network_predict returns. */
+float *y2_network_predict_device(network net, const float *d_input);
+/* Forward only (no host copy of the output); then decode+NMS+collect with y2_detect_resident. */
+int y2_forward_device(network net, const float *d_input);
+/* Decode + per-class NMS + compaction of the last forward, all on device; up to max_per_image
+ * detections per image are written to dets[b*max_per_image ...], counts[b] = number found. */
+int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_h,
+                       y2_det *dets, int *counts, int max_per_image);
+/* Host-input convenience: H2D + forward + y2_detect_resident. */
+int y2_detect(network net, float *input, float thresh, float nms, int img_w, int img_h,
+              y2_det *dets, int *counts, int max_per_image);
+/* Copy layer i's activations to host as NCHW [batch][out_c][out_h][out_w] (or [batch][outputs]). */
+int y2_pull_layer_output(network net, int i, float *dst);
+/* Per-layer device time of the last forward in ms (needs y2_set_timing(net,1)); returns layers written. */
+void y2_set_timing(network *net, int on);
+int y2_layer_times_ms(network net, float *ms, int max_layers);
+/* Name of the kernel a layer runs ("conv_mfma_f32_128x128x32_k3", "maxpool", ...). */
+const char *y2_layer_kernel(network net, int i);
+/* Stream the engine launches on (hipStream_t) and a whole-device sync. */
+void *y2_stream(network net);
+void y2_sync(network net);
+/* Last error text of the library (never NULL). */
+const char *y2_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR_YOLO2_H */

@@ -1,0 +1,169 @@
+/*
+ * y2_hip.h -- the thin C-ABI device layer of the MI355X (gfx950) YOLOv2 engine.
+ *
+ * Everything the C host code (csrc/host, C sources) needs from the GPU goes through
+ * these entry points: plain pointers and sizes, no C++ or torch types.  It
+ * replaces the reference's device wrapper and its per-layer *_gpu functions:
+ *
+ *   device/memory      src_yolo2/cuda.h:24-33  (cuda_set_device, cuda_make_array,
+ *                      cuda_push_array, cuda_pull_array, cuda_free, check_error)
+ *   conv+BN+bias+act   src_yolo2/convolutional_kernels.cu:77-131
+ *                      (fill + im2col_ongpu + gemm_ongpu + normalize_gpu +
+ *                       scale_bias_gpu + add_bias_gpu + activate_array_ongpu,
+ *                       >= 6 launches per layer there; ONE launch here)
+ *   maxpool            src_yolo2/maxpool_layer_kernels.cu:87-97
+ *   reorg              src_yolo2/reorg_layer.c:97-104 (reorg_ongpu, blas_kernels.cu:332)
+ *   route              src_yolo2/route_layer.c:104-117 (copy_ongpu per input per item)
+ *   region head        src_yolo2/region_layer.c:383-417 (flatten_ongpu + softmax_gpu,
+ *                      then D2H and logistic on the CPU there; all on device here)
+ *   decode / NMS       src_yolo2/region_layer.c:328-379, src_yolo2/box.c:249-277
+ *                      (CPU-only in the reference, both builds)
+ *   avgpool / softmax  src_yolo2/avgpool_layer_kernels.cu:44, src_yolo2/softmax_layer.c:73
+ *
+ * Data layout: activations are NHWC fp32 with an explicit channel stride
+ * (`ld`, in floats) so that [route] concatenation is a channel-offset write
+ * instead of a copy.  Convolution weights are pre-packed per layer as
+ * [Cout][kh][kw][Cin] (K index = (kh*size + kw)*Cin + ci).
+ *
+ * All functions return 0 on success or a negative Y2H_E* code; none aborts.
+ * The legacy abort-on-error contract (cuda.c:27-49 check_error) is applied one
+ * level up, in the host C layer.
+ */
+#ifndef Y2_HIP_H
+#define Y2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y2H_OK            0
+#define Y2H_EHIP         -1   /* a HIP runtime call failed (y2h_last_error() has the text) */
+#define Y2H_EINVAL       -2   /* argument outside what the kernels support */
+#define Y2H_ENODEV       -3   /* no gfx950 device visible */
+
+typedef void *y2h_stream;   /* hipStream_t */
+typedef void *y2h_event;    /* hipEvent_t */
+
+/* activation codes (subset of src_yolo2/activations.h:7 used by the target cfgs) */
+enum { Y2H_ACT_LINEAR = 0, Y2H_ACT_LEAKY = 1, Y2H_ACT_LOGISTIC = 2, Y2H_ACT_RELU = 3 };
+
+/* ---- device / memory / streams (cuda.h:24-33) ---- */
+int         y2h_device_count(void);
+int         y2h_set_device(int dev);
+int         y2h_get_device(int *dev);
+const char *y2h_last_error(void);
+const char *y2h_device_name(void);
+int         y2h_malloc(void **ptr, size_t bytes);
+int         y2h_free(void *ptr);
+int         y2h_host_alloc(void **ptr, size_t bytes);           /* pinned host memory */
+int         y2h_host_free(void *ptr);
+int         y2h_memcpy_h2d(void *dst, const void *src, size_t bytes, y2h_stream s);
+int         y2h_memcpy_d2h(void *dst, const void *src, size_t bytes, y2h_stream s);
+int         y2h_memcpy_d2d(void *dst, const void *src, size_t bytes, y2h_stream s);
+int         y2h_memset(void *dst, int value, size_t bytes, y2h_stream s);
+int         y2h_stream_create(y2h_stream *s);
+int         y2h_stream_destroy(y2h_stream s);
+int         y2h_stream_sync(y2h_stream s);
+int         y2h_device_sync(void);
+int         y2h_event_create(y2h_event *e);
+int         y2h_event_destroy(y2h_event e);
+int         y2h_event_record(y2h_event e, y2h_stream s);
+int         y2h_event_elapsed_ms(y2h_event start, y2h_event stop, float *ms);   /* syncs on stop */
+
+/* ---- layout ---- */
+/* [n][c][h][w] -> [n][h][w][ld] (channels 0..c-1 of each pixel row) and back */
+int y2h_nchw_to_nhwc(const float *src, float *dst, int n, int c, int h, int w, int ld, y2h_stream s);
+int y2h_nhwc_to_nchw(const float *src, int ld, float *dst, int n, int c, int h, int w, y2h_stream s);
+/* copy `c` channels of `npix` pixels between two NHWC buffers ([route] fallback) */
+int y2h_copy_channels(const float *src, int ld_src, float *dst, int ld_dst, int c, long npix, y2h_stream s);
+
+/* ---- convolution + fused epilogue ---- */
+typedef struct y2h_conv {
+    int batch, h, w, c;          /* input  NHWC dims                                   */
+    int ldx;                     /* input  channel stride (floats)                     */
+    int n;                       /* filters (output channels)                          */
+    int size, stride, pad;       /* square kernel                                      */
+    int out_h, out_w;
+    int ldy;                     /* output channel stride (floats)                     */
+    int batch_normalize;         /* 1: (x-mean)*rinv*scale + bias ; 0: x + bias        */
+    int activation;              /* Y2H_ACT_*                                          */
+    const float  *x;             /* device, NHWC                                       */
+    const float  *w_packed;      /* device, [n][size][size][c]                         */
+    const float  *w_ref;         /* device, [n][c][size][size] (strict path only) or 0 */
+    const float  *mean;          /* device [n]  rolling_mean        (BN only)          */
+    const double *rinv;          /* device [n]  1/(sqrt((double)var)+1e-6f) (BN only)  */
+    const float  *scale;         /* device [n]  scales              (BN only)          */
+    const float  *bias;          /* device [n]                                         */
+    float        *y;             /* device, NHWC (already offset to the first channel) */
+} y2h_conv;
+
+/* which kernel y2h_conv_forward would pick: 1 = MFMA implicit GEMM, 0 = direct VALU */
+int y2h_conv_uses_mfma(const y2h_conv *d);
+/* strict != 0 forces the direct kernel, which accumulates in the reference's exact
+ * order (ci, kh, kw ascending; product and sum rounded separately: gemm.c:74-88)
+ * and is therefore bit-identical to the CPU path; needs w_ref. */
+int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s);
+/* name of the kernel variant last chosen for this descriptor (for profiles) */
+const char *y2h_conv_variant(const y2h_conv *d, int strict);
+
+/* ---- other layers (NHWC) ---- */
+int y2h_maxpool(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c,
+                int size, int stride, int pad, int out_h, int out_w, y2h_stream s);
+/* the reference's reorg quirk (blas.c:8-29 called with forward=0 for a non-reverse
+ * layer, reorg_layer.c:83), re-expressed for NHWC in and out; reverse!=0 is forward=1 */
+int y2h_reorg(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c,
+              int stride, int reverse, y2h_stream s);
+/* global average pool: [batch][h*w][ld] -> [batch][c] (sequential fp32 sum, avgpool_layer.c:40) */
+int y2h_avgpool(const float *x, int ldx, float *y, int batch, int h, int w, int c, y2h_stream s);
+/* rows of `n` floats: softmax with temperature (blas.c:205); in/out may alias */
+int y2h_softmax_rows(const float *x, float *y, long rows, int n, float temp, y2h_stream s);
+
+/* ---- region head ---- */
+/* x: last conv output NHWC [batch][h*w][ldx] holding num*(coords+1+classes) channels.
+ * y: [batch][h*w*num][coords+1+classes] (the reference's flattened layout).
+ * logistic on objectness, softmax (softmax!=0) or per-group tree softmax
+ * (group_size/group_offset device arrays, groups>0) on the class scores. */
+int y2h_region_forward(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
+                       int softmax, int groups, const int *group_size, const int *group_offset, y2h_stream s);
+
+typedef struct y2h_decode {
+    int batch, w, h, num, classes;
+    int img_w, img_h;               /* the (w,h) scale arguments of get_region_boxes   */
+    float thresh;
+    int only_objectness;
+    int classfix;
+    const float *anchors;           /* device [2*num]  (l.biases)                      */
+    const int   *tree_parent;       /* device [classes] or 0 (softmax_tree)            */
+    const int   *map;               /* device [200] or 0                               */
+    float       *pred;              /* device region output [batch][w*h*num][5+classes];
+                                       the tree branch updates it in place, as the
+                                       reference does (region_layer.c:350)            */
+    float       *boxes;             /* device out [batch][w*h*num][4]                  */
+    float       *probs;             /* device out [batch][w*h*num][classes]            */
+} y2h_decode;
+int y2h_region_boxes(const y2h_decode *d, y2h_stream s);
+
+/* per-class sort + greedy suppression on device arrays, box.c:249-277.
+ * probs rows have `stride` floats; only the first `classes` columns take part. */
+int y2h_nms_sort(const float *boxes, float *probs, int batch, int total, int classes, int stride,
+                 float thresh, y2h_stream s);
+/* class-agnostic variant, box.c:279-298 */
+int y2h_nms(const float *boxes, float *probs, int batch, int total, int classes, int stride,
+            float thresh, y2h_stream s);
+
+/* compact detections per image in ascending box order (yolo_v2_class.cpp:221-238,
+ * image.c:662-738): record = {x,y,w,h,prob,class} (6 floats); counts[b] = number found
+ * (may exceed max_per_image; only the first max_per_image are stored). */
+int y2h_collect(const float *boxes, const float *probs, int batch, int total, int classes, int stride,
+                float thresh, float *records, int *counts, int max_per_image, y2h_stream s);
+
+/* separable align-corners bilinear resize of a CHW image (image.c:1950-1992) */
+int y2h_resize_chw(const float *src, int c, int ih, int iw, float *tmp, float *dst, int h, int w, y2h_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Y2_HIP_H */

@@ -1,0 +1,304 @@
+/*
+ * Region-head hand-off on the host side: the reference's CPU functions
+ * get_region_boxes (src_yolo2/region_layer.c:328-379), do_nms_sort / do_nms
+ * (src_yolo2/box.c:249-298), the Kinect entry test_detector_img
+ * (src_yolo2/detector.c:558-598 + draw_detections_test image.c:662-738) and
+ * the small helpers around them -- all backed by the device kernels of
+ * y2_detect.hip.  The legacy signatures take caller-owned HOST arrays
+ * (probs is float*[total], boxes is box[total]); they are honoured by staging
+ * through HBM, so there is no CPU implementation of decode or NMS in this
+ * library.  y2_detect*() is the fused, HBM-resident form the Detector class
+ * and bench.py use: forward -> decode -> NMS -> compaction with only the
+ * compact detection records crossing PCIe.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "y2_internal.h"
+
+#define HIPCALL(expr) do { int rc_ = (expr); if (rc_ != 0) { y2_fail("%s failed (%d): %s", #expr, rc_, y2h_last_error()); return; } } while (0)
+#define HIPCALL_I(expr) do { int rc_ = (expr); if (rc_ != 0) { y2_fail("%s failed (%d): %s", #expr, rc_, y2h_last_error()); return -1; } } while (0)
+
+static y2_ldev *ld_of(const layer *l) { return (y2_ldev *)l->dev; }
+
+/* get_region_boxes: l.output is a HOST pointer the caller may have replaced
+ * (yolo_v2_class.cpp:211 substitutes the 3-frame mean).  When it still is the
+ * engine's own output buffer the tensor is already in HBM and is not re-sent. */
+void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *boxes, int only_objectness, int *map)
+{
+    y2_ldev *d = ld_of(&l);
+    y2_engine *e;
+    y2h_decode q;
+    int total = l.w * l.h * l.n, i;
+    size_t pred_floats = (size_t)total * (l.classes + 5);
+    float *d_pred, *d_tmp_pred = NULL, *h_probs;
+    int *d_tmp_map = NULL;
+    if (l.type != REGION || !d || !d->eng || !d->eng->built) { y2_fail("get_region_boxes: layer is not a prepared region layer"); return; }
+    e = d->eng;
+    HIPCALL(y2h_set_device(e->device));
+    memset(&q, 0, sizeof q);
+    q.batch = 1; q.w = l.w; q.h = l.h; q.num = l.n; q.classes = l.classes;
+    q.img_w = w; q.img_h = h; q.thresh = thresh; q.only_objectness = only_objectness; q.classfix = l.classfix;
+    q.anchors = d->d_anchors;
+    q.tree_parent = l.softmax_tree ? d->d_tree_parent : NULL;
+    if (l.output >= e->h_out && l.output < e->h_out + e->out_floats && (size_t)(l.output - e->h_out) % l.outputs == 0) {
+        d_pred = d->d_region + (l.output - e->h_out);           /* batch item (l.output - h_out)/outputs */
+    } else {
+        HIPCALL(y2h_malloc((void **)&d_tmp_pred, pred_floats * sizeof(float)));
+        HIPCALL(y2h_memcpy_h2d(d_tmp_pred, l.output, pred_floats * sizeof(float), e->stream));
+        d_pred = d_tmp_pred;
+    }
+    if (map && l.softmax_tree) {
+        if (map == l.map && d->d_map) q.map = d->d_map;
+        else {
+            HIPCALL(y2h_malloc((void **)&d_tmp_map, 200 * sizeof(int)));
+            HIPCALL(y2h_memcpy_h2d(d_tmp_map, map, 200 * sizeof(int), e->stream));
+            q.map = d_tmp_map;
+        }
+    }
+    q.pred = d_pred; q.boxes = e->d_boxes; q.probs = e->d_probs;
+    if (q.map) HIPCALL(y2h_memset(e->d_probs, 0, (size_t)total * l.classes * sizeof(float), e->stream));
+    HIPCALL(y2h_region_boxes(&q, e->stream));
+    h_probs = malloc((size_t)total * l.classes * sizeof(float));
+    HIPCALL(y2h_memcpy_d2h(boxes, e->d_boxes, (size_t)total * sizeof(box), e->stream));
+    HIPCALL(y2h_memcpy_d2h(h_probs, e->d_probs, (size_t)total * l.classes * sizeof(float), e->stream));
+    if (l.softmax_tree)      /* the reference rewrites the class scores in l.output in place (region_layer.c:350) */
+        HIPCALL(y2h_memcpy_d2h(l.output, d_pred, pred_floats * sizeof(float), e->stream));
+    HIPCALL(y2h_stream_sync(e->stream));
+    {
+        int ncopy = (q.map) ? 200 : l.classes;               /* with a map only 200 entries per row are written */
+        for (i = 0; i < total; ++i) memcpy(probs[i], h_probs + (size_t)i * l.classes, ncopy * sizeof(float));
+        if (q.map && only_objectness) for (i = 0; i < total; ++i) probs[i][0] = h_probs[(size_t)i * l.classes];
+    }
+    free(h_probs);
+    y2h_free(d_tmp_pred);
+    y2h_free(d_tmp_map);
+}
+
+/* scratch for the array-in/array-out NMS entry points (not thread-safe, like the reference) */
+static struct { float *d_boxes, *d_probs; size_t boxes_cap, probs_cap; y2h_stream stream; int device; } g_nms = {0, 0, 0, 0, 0, -1};
+
+static int nms_scratch(size_t nboxes, size_t nprobs)
+{
+    int dev = 0;
+    if (y2h_device_count() <= 0) { y2_fail("do_nms: no HIP device visible and this library has no CPU path"); return -1; }
+    HIPCALL_I(y2h_get_device(&dev));
+    if (g_nms.device != dev) {
+        g_nms.d_boxes = g_nms.d_probs = NULL; g_nms.boxes_cap = g_nms.probs_cap = 0; g_nms.stream = NULL;   /* per-device scratch */
+        g_nms.device = dev;
+    }
+    if (!g_nms.stream) HIPCALL_I(y2h_stream_create(&g_nms.stream));
+    if (nboxes > g_nms.boxes_cap) { y2h_free(g_nms.d_boxes); HIPCALL_I(y2h_malloc((void **)&g_nms.d_boxes, nboxes * sizeof(float))); g_nms.boxes_cap = nboxes; }
+    if (nprobs > g_nms.probs_cap) { y2h_free(g_nms.d_probs); HIPCALL_I(y2h_malloc((void **)&g_nms.d_probs, nprobs * sizeof(float))); g_nms.probs_cap = nprobs; }
+    return 0;
+}
+
+static void nms_host(box *boxes, float **probs, int total, int classes, float thresh, int sorted)
+{
+    float *flat;
+    int i;
+    if (total <= 0 || classes <= 0) return;
+    if (nms_scratch((size_t)total * 4, (size_t)total * classes) != 0) return;
+    flat = malloc((size_t)total * classes * sizeof(float));
+    for (i = 0; i < total; ++i) memcpy(flat + (size_t)i * classes, probs[i], classes * sizeof(float));
+    HIPCALL(y2h_memcpy_h2d(g_nms.d_boxes, boxes, (size_t)total * sizeof(box), g_nms.stream));
+    HIPCALL(y2h_memcpy_h2d(g_nms.d_probs, flat, (size_t)total * classes * sizeof(float), g_nms.stream));
+    if (sorted) HIPCALL(y2h_nms_sort(g_nms.d_boxes, g_nms.d_probs, 1, total, classes, classes, thresh, g_nms.stream));
+    else HIPCALL(y2h_nms(g_nms.d_boxes, g_nms.d_probs, 1, total, classes, classes, thresh, g_nms.stream));
+    HIPCALL(y2h_memcpy_d2h(flat, g_nms.d_probs, (size_t)total * classes * sizeof(float), g_nms.stream));
+    HIPCALL(y2h_stream_sync(g_nms.stream));
+    for (i = 0; i < total; ++i) memcpy(probs[i], flat + (size_t)i * classes, classes * sizeof(float));
+    free(flat);
+}
+
+void do_nms_sort(box *boxes, float **probs, int total, int classes, float thresh) { nms_host(boxes, probs, total, classes, thresh, 1); }
+void do_nms(box *boxes, float **probs, int total, int classes, float thresh) { nms_host(boxes, probs, total, classes, thresh, 0); }
+
+/* box.c:67-97.  A scalar helper on host values (two boxes in, one float out); kept on the
+ * host because a kernel launch per call would be absurd.  Same expression order as the reference. */
+static float overlap1(float x1, float w1, float x2, float w2)
+{
+    float l1 = x1 - w1 / 2, l2 = x2 - w2 / 2;
+    float left = l1 > l2 ? l1 : l2;
+    float r1 = x1 + w1 / 2, r2 = x2 + w2 / 2;
+    float right = r1 < r2 ? r1 : r2;
+    return right - left;
+}
+float box_iou(box a, box b)
+{
+    float w = overlap1(a.x, a.w, b.x, b.w), h = overlap1(a.y, a.h, b.y, b.h);
+    float inter = (w < 0 || h < 0) ? 0 : w * h;
+    float uni = a.w * a.h + b.w * b.h - inter;
+    return inter / uni;
+}
+box float_to_box(float *f) { box b; b.x = f[0]; b.y = f[1]; b.w = f[2]; b.h = f[3]; return b; }
+
+int max_index(float *a, int n)               /* utils.c:533-545 */
+{
+    int i, mi = 0;
+    float m;
+    if (n <= 0) return -1;
+    m = a[0];
+    for (i = 1; i < n; ++i) if (a[i] > m) { m = a[i]; mi = i; }
+    return mi;
+}
+
+void top_k(float *a, int n, int k, int *index)   /* utils.c:179-193 */
+{
+    int i, j;
+    for (j = 0; j < k; ++j) index[j] = -1;
+    for (i = 0; i < n; ++i) {
+        int curr = i;
+        for (j = 0; j < k && curr >= 0; ++j)
+            if (index[j] < 0 || a[curr] > a[index[j]]) { int s = curr; curr = index[j]; index[j] = s; }
+    }
+}
+
+void mean_arrays(float **a, int n, int els, float *avg)   /* utils.c:420-432 */
+{
+    int i, j;
+    memset(avg, 0, (size_t)els * sizeof(float));
+    for (j = 0; j < n; ++j) for (i = 0; i < els; ++i) avg[i] += a[j][i];
+    for (i = 0; i < els; ++i) avg[i] /= n;
+}
+
+float get_color(int c, int x, int max)       /* image.c:33-42 */
+{
+    static const float colors[6][3] = { {1,0,1}, {0,0,1}, {0,1,1}, {0,1,0}, {1,1,0}, {1,0,0} };
+    float ratio = ((float)x / max) * 5;
+    int i = (int)floor(ratio), j = (int)ceil(ratio);
+    ratio -= i;
+    return (1 - ratio) * colors[i][c] + ratio * colors[j][c];
+}
+
+image make_image(int w, int h, int c)        /* image.c:1436 */
+{
+    image im;
+    im.w = w; im.h = h; im.c = c;
+    im.data = calloc((size_t)w * h * c > 0 ? (size_t)w * h * c : 1, sizeof(float));
+    return im;
+}
+void free_image(image m) { free(m.data); }
+
+image resize_image(image im, int w, int h)   /* image.c:1950-1992, on the device */
+{
+    image out = make_image(w, h, im.c);
+    float *d_src = NULL, *d_tmp = NULL, *d_dst = NULL;
+    y2h_stream s = NULL;
+    size_t ns = (size_t)im.w * im.h * im.c, nt = (size_t)w * im.h * im.c, nd = (size_t)w * h * im.c;
+    if (y2h_device_count() <= 0) { y2_fail("resize_image: no HIP device visible and this library has no CPU path"); return out; }
+    if (gpu_index >= 0) y2h_set_device(gpu_index);
+    if (y2h_stream_create(&s) || y2h_malloc((void **)&d_src, ns * 4) || y2h_malloc((void **)&d_tmp, nt * 4) ||
+        y2h_malloc((void **)&d_dst, nd * 4) || y2h_memcpy_h2d(d_src, im.data, ns * 4, s) ||
+        y2h_resize_chw(d_src, im.c, im.h, im.w, d_tmp, d_dst, h, w, s) || y2h_memcpy_d2h(out.data, d_dst, nd * 4, s) ||
+        y2h_stream_sync(s))
+        y2_fail("resize_image: %s", y2h_last_error());
+    y2h_free(d_src); y2h_free(d_tmp); y2h_free(d_dst);
+    y2h_stream_destroy(s);
+    return out;
+}
+
+/* ------------------------------------------------------------------ */
+/* fused, HBM-resident detection                                       */
+/* ------------------------------------------------------------------ */
+int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_h,
+                       y2_det *dets, int *counts, int max_per_image)
+{
+    y2_engine *e = y2_engine_of(&net);
+    layer *l;
+    y2_ldev *d;
+    y2h_decode q;
+    int b, i, keep;
+    if (!e || !e->built) { y2_fail("y2_detect_resident: run a forward first"); return -1; }
+    l = &net.layers[e->out_layer];
+    d = ld_of(l);
+    if (l->type != REGION) { y2_fail("y2_detect_resident: the network does not end in a region layer"); return -1; }
+    HIPCALL_I(y2h_set_device(e->device));
+    memset(&q, 0, sizeof q);
+    q.batch = net.batch; q.w = l->w; q.h = l->h; q.num = l->n; q.classes = l->classes;
+    q.img_w = img_w; q.img_h = img_h; q.thresh = thresh; q.classfix = l->classfix;
+    q.anchors = d->d_anchors;
+    q.tree_parent = l->softmax_tree ? d->d_tree_parent : NULL;
+    q.pred = d->d_region; q.boxes = e->d_boxes; q.probs = e->d_probs;
+    HIPCALL_I(y2h_region_boxes(&q, e->stream));
+    if (nms > 0)
+        HIPCALL_I(y2h_nms_sort(e->d_boxes, e->d_probs, net.batch, e->det_total, l->classes, l->classes, nms, e->stream));
+    HIPCALL_I(y2h_collect(e->d_boxes, e->d_probs, net.batch, e->det_total, l->classes, l->classes, thresh,
+                          e->d_records, e->d_counts, e->det_cap, e->stream));
+    HIPCALL_I(y2h_memcpy_d2h(e->h_counts, e->d_counts, (size_t)net.batch * sizeof(int), e->stream));
+    HIPCALL_I(y2h_stream_sync(e->stream));
+    keep = 0;
+    for (b = 0; b < net.batch; ++b) if (e->h_counts[b] > keep) keep = e->h_counts[b];
+    if (keep > e->det_cap) keep = e->det_cap;
+    if (keep > 0) {
+        /* one strided copy of the used prefix of every image's record block */
+        for (b = 0; b < net.batch; ++b) {
+            int nb = e->h_counts[b] < e->det_cap ? e->h_counts[b] : e->det_cap;
+            if (nb > 0)
+                HIPCALL_I(y2h_memcpy_d2h(e->h_records + (size_t)b * e->det_cap * 6, e->d_records + (size_t)b * e->det_cap * 6,
+                                         (size_t)nb * 6 * sizeof(float), e->stream));
+        }
+        HIPCALL_I(y2h_stream_sync(e->stream));
+    }
+    for (b = 0; b < net.batch; ++b) {
+        int nb = e->h_counts[b];
+        counts[b] = nb;
+        if (nb > e->det_cap) nb = e->det_cap;
+        if (nb > max_per_image) nb = max_per_image;
+        for (i = 0; i < nb; ++i) {
+            const float *r = e->h_records + ((size_t)b * e->det_cap + i) * 6;
+            y2_det *o = &dets[(size_t)b * max_per_image + i];
+            o->x = r[0]; o->y = r[1]; o->w = r[2]; o->h = r[3]; o->prob = r[4]; o->obj_id = (int)r[5];
+        }
+    }
+    return 0;
+}
+
+int y2_detect(network net, float *input, float thresh, float nms, int img_w, int img_h,
+              y2_det *dets, int *counts, int max_per_image)
+{
+    y2_engine *e;
+    if (y2_prepare(&net) != 0) return -1;
+    e = y2_engine_of(&net);
+    HIPCALL_I(y2h_memcpy_h2d(e->d_in_nchw, input, e->in_floats * sizeof(float), e->stream));
+    if (y2_forward_device(net, e->d_in_nchw) != 0) return -1;
+    return y2_detect_resident(net, thresh, nms, img_w, img_h, dets, counts, max_per_image);
+}
+
+/* detector.c:558-598 test_detector_img: resize -> predict -> get_region_boxes(1,1,thresh) ->
+ * do_nms_sort(nms=0.1) -> draw_detections_test, which fills RecObects (image.c:662-738).
+ * Reads exactly net.inputs floats of the resized image (planes 0..2; a 4th plane is ignored). */
+void test_detector_img(char **names, image **alphabet, network net, image im, float thresh,
+                       object *RecObects, int *objectNumPerFrame)
+{
+    const float nms = 0.1f;
+    image sized = resize_image(im, net.w, net.h);
+    layer l = net.layers[net.n - 1];
+    int total = l.w * l.h * l.n, n, i;
+    y2_det *dets;
+    int count = 0;
+    (void)alphabet;
+    if (y2_failed()) { free_image(sized); return; }
+    if (net.batch != 1) { free_image(sized); y2_fail("test_detector_img: set_batch_network(&net, 1) first"); return; }
+    dets = calloc(total > 0 ? total : 1, sizeof(y2_det));
+    if (y2_detect(net, sized.data, thresh, nms, 1, 1, dets, &count, total) != 0) { free(dets); free_image(sized); return; }
+    n = count < total ? count : total;
+    for (i = 0; i < n; ++i) {
+        object *o = &RecObects[*objectNumPerFrame];
+        int cls = dets[i].obj_id;
+        int offset = cls * 123457 % l.classes;
+        if (names) printf("%s: %.0f%%\n", names[cls], dets[i].prob * 100);
+        o->x = dets[i].x; o->y = dets[i].y; o->w = dets[i].w; o->h = dets[i].h;
+        o->prob = dets[i].prob;
+        o->objClass = cls;
+        if (names && names[cls]) { strncpy(o->name, names[cls], sizeof o->name - 1); o->name[sizeof o->name - 1] = 0; }
+        else o->name[0] = 0;
+        o->boxRGB[0] = get_color(2, offset, l.classes);
+        o->boxRGB[1] = get_color(1, offset, l.classes);
+        o->boxRGB[2] = get_color(0, offset, l.classes);
+        (*objectNumPerFrame)++;
+    }
+    free(dets);
+    free_image(sized);
+}

@@ -1,0 +1,743 @@
+/*
+ * Network runtime: buffer plan, weight arena and the forward pass.
+ *
+ * Host-side replacement for src_yolo2/network.c (forward_network :145,
+ * network_predict :458, set_batch_network :308, resize_network :322,
+ * free_network :592) and src_yolo2/network_kernels.cu (forward_network_gpu :43,
+ * network_predict_gpu :392), re-designed for one MI355X:
+ *
+ *  - activations are NHWC in HBM and never leave it between layers; there is
+ *    no im2col workspace, no per-call cudaMalloc/H2D/cudaFree
+ *    (network_kernels.cu:399,405), no per-layer fill of `delta`
+ *    (network_kernels.cu:50-52);
+ *  - [route] is planned away: a one-input route aliases its source, and the
+ *    sources of a concatenating route write straight into the route's buffer
+ *    at their channel offset (conv / maxpool / reorg kernels take an output
+ *    channel stride), so the copy_ongpu launches of route_layer.c:104-117
+ *    disappear; a copy kernel remains only for sources that cannot be placed;
+ *  - all weights sit in ONE device allocation ("arena") in kernel layout
+ *    ([n][kh][kw][c] filters + the per-filter epilogue constants), so that a
+ *    multi-GPU launcher replicates the model with a single broadcast;
+ *  - the plan is built lazily at the first predict after parse / resize /
+ *    set_batch, which also lets set_batch_network grow the batch safely.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "y2_internal.h"
+
+#define HIPCALL(expr) do { int rc_ = (expr); if (rc_ != 0) { y2_fail("%s failed (%d): %s", #expr, rc_, y2h_last_error()); return -1; } } while (0)
+
+static y2_ldev *ld_of(const layer *l) { return (y2_ldev *)l->dev; }
+
+y2_engine *y2_engine_of(const network *net) { return net ? (y2_engine *)net->engine : NULL; }
+
+int y2_engine_create(network *net)
+{
+    y2_engine *e = calloc(1, sizeof *e);
+    int i;
+    const char *st = getenv("Y2_STRICT");
+    e->device = net->gpu_index;
+    e->weights_dirty = 1;
+    e->strict = (st && atoi(st) != 0) ? 1 : 0;
+    e->n_layers = net->n;
+    e->out_layer = y2_out_layer(net);
+    for (i = 0; i < net->n; ++i) {
+        y2_ldev *d = calloc(1, sizeof *d);
+        d->eng = e;
+        d->index = i;
+        d->placed_in = -1;
+        d->alias_of = -1;
+        net->layers[i].dev = d;
+    }
+    net->engine = e;
+    return 0;
+}
+
+static void free_plan(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    int i;
+    if (!e) return;
+    for (i = 0; i < net->n; ++i) {
+        y2_ldev *d = ld_of(&net->layers[i]);
+        if (!d) continue;
+        y2h_free(d->out_alloc); d->out_alloc = NULL; d->out = NULL;
+        y2h_free(d->d_region); d->d_region = NULL;
+        y2h_free(d->d_flat); d->d_flat = NULL;
+        d->placed_in = -1; d->alias_of = -1; d->copy_mask = 0;
+    }
+    y2h_free(e->d_in_nchw); e->d_in_nchw = NULL;
+    y2h_free(e->d_in_nhwc); e->d_in_nhwc = NULL;
+    y2h_free(e->d_out_nchw); e->d_out_nchw = NULL;
+    y2h_host_free(e->h_out); e->h_out = NULL;
+    y2h_free(e->d_boxes); e->d_boxes = NULL;
+    y2h_free(e->d_probs); e->d_probs = NULL;
+    y2h_free(e->d_records); e->d_records = NULL;
+    y2h_free(e->d_counts); e->d_counts = NULL;
+    y2h_host_free(e->h_records); e->h_records = NULL;
+    y2h_host_free(e->h_counts); e->h_counts = NULL;
+    if (net->layers) net->layers[e->out_layer].output = NULL;
+    e->built = 0;
+}
+
+void y2_engine_invalidate(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (e) e->built = 0;
+}
+
+void y2_engine_destroy(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    int i;
+    if (!e) return;
+    if (e->stream || e->arena || e->built) y2h_set_device(e->device);
+    free_plan(net);
+    for (i = 0; i < net->n; ++i) {
+        y2_ldev *d = ld_of(&net->layers[i]);
+        if (!d) continue;
+        y2h_free(d->d_anchors); y2h_free(d->d_tree_parent); y2h_free(d->d_tree_gsize); y2h_free(d->d_tree_goff); y2h_free(d->d_map);
+        free(d);
+        net->layers[i].dev = NULL;
+    }
+    y2h_free(e->arena);
+    if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
+    y2h_stream_destroy(e->stream);
+    free(e);
+    net->engine = NULL;
+}
+
+/* ------------------------------------------------------------------ */
+/* plan                                                                */
+/* ------------------------------------------------------------------ */
+static int producer_can_place(const layer *l)
+{
+    return l->type == CONVOLUTIONAL || l->type == MAXPOOL || l->type == REORG;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, int ldx)
+{
+    const layer *l = &net->layers[i];
+    const y2_ldev *d = ld_of(l);
+    const y2_engine *e = d->eng;
+    memset(c, 0, sizeof *c);
+    c->batch = l->batch; c->h = l->h; c->w = l->w; c->c = l->c; c->ldx = ldx;
+    c->n = l->n; c->size = l->size; c->stride = l->stride; c->pad = l->pad;
+    c->out_h = l->out_h; c->out_w = l->out_w; c->ldy = d->out_ld;
+    c->batch_normalize = l->batch_normalize;
+    switch (l->activation) {
+    case LINEAR: c->activation = Y2H_ACT_LINEAR; break;
+    case LEAKY: c->activation = Y2H_ACT_LEAKY; break;
+    case LOGISTIC: c->activation = Y2H_ACT_LOGISTIC; break;
+    case RELU: c->activation = Y2H_ACT_RELU; break;
+    default: c->activation = -1; break;
+    }
+    c->x = x;
+    c->y = d->out;
+    if (e->arena) {
+        c->w_packed = (const float *)(e->arena + d->off_w_packed);
+        c->w_ref = d->has_w_ref ? (const float *)(e->arena + d->off_w_ref) : NULL;
+        c->bias = (const float *)(e->arena + d->off_bias);
+        if (l->batch_normalize) {
+            c->mean = (const float *)(e->arena + d->off_mean);
+            c->scale = (const float *)(e->arena + d->off_scale);
+            c->rinv = (const double *)(e->arena + d->off_rinv);
+        }
+    }
+}
+
+static void input_view(const network *net, int i, const float **x, int *ldx)
+{
+    const y2_engine *e = y2_engine_of(net);
+    if (i == 0) { *x = e->d_in_nhwc; *ldx = net->c; }
+    else { const y2_ldev *p = ld_of(&net->layers[i - 1]); *x = p->out; *ldx = p->out_ld; }
+}
+
+static int upload_small(void **dst, const void *src, size_t bytes, y2h_stream s)
+{
+    if (*dst) { y2h_free(*dst); *dst = NULL; }
+    if (y2h_malloc(dst, bytes) != 0) return -1;
+    if (y2h_memcpy_h2d(*dst, src, bytes, s) != 0) return -1;
+    return y2h_stream_sync(s);
+}
+
+static int upload_weights(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    unsigned char *host = calloc(1, e->arena_bytes ? e->arena_bytes : 16);
+    int i;
+    for (i = 0; i < net->n; ++i) {
+        const layer *l = &net->layers[i];
+        const y2_ldev *d = ld_of(l);
+        float *wp, *b;
+        int K, co, ci, kh, kw, f;
+        if (l->type != CONVOLUTIONAL) continue;
+        K = l->size * l->size * l->c;
+        wp = (float *)(host + d->off_w_packed);
+        /* reference layout [n][c][kh][kw] (im2col.c:24-27) -> kernel layout [n][kh][kw][c] */
+        for (co = 0; co < l->n; ++co)
+            for (ci = 0; ci < l->c; ++ci)
+                for (kh = 0; kh < l->size; ++kh)
+                    for (kw = 0; kw < l->size; ++kw)
+                        wp[(size_t)co * K + (size_t)(kh * l->size + kw) * l->c + ci] =
+                            l->weights[(((size_t)co * l->c + ci) * l->size + kh) * l->size + kw];
+        if (d->has_w_ref) memcpy(host + d->off_w_ref, l->weights, (size_t)l->n * K * sizeof(float));
+        b = (float *)(host + d->off_bias);
+        memcpy(b, l->biases, l->n * sizeof(float));
+        if (l->batch_normalize) {
+            double *r = (double *)(host + d->off_rinv);
+            memcpy(host + d->off_mean, l->rolling_mean, l->n * sizeof(float));
+            memcpy(host + d->off_scale, l->scales, l->n * sizeof(float));
+            /* blas.c:122: x / (sqrt(variance) + .000001f), the divisor evaluated in double */
+            for (f = 0; f < l->n; ++f) r[f] = 1.0 / (sqrt((double)l->rolling_variance[f]) + (double).000001f);
+        }
+    }
+    if (y2h_memcpy_h2d(e->arena, host, e->arena_bytes, e->stream) != 0 || y2h_stream_sync(e->stream) != 0) {
+        free(host);
+        y2_fail("weight upload failed: %s", y2h_last_error());
+        return -1;
+    }
+    free(host);
+    e->weights_dirty = 0;
+    return 0;
+}
+
+int y2_engine_build(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    int i, k;
+    size_t off;
+    if (!e) { y2_fail("network has no engine (was it built by parse_network_cfg?)"); return -1; }
+    if (net->gpu_index < 0) {
+        y2_fail("gpu_index %d: this library has no CPU compute path; select a GPU (>= 0)", net->gpu_index);
+        return -1;
+    }
+    if (y2h_device_count() <= 0) { y2_fail("no HIP device visible: the MI355X engine cannot run"); return -1; }
+    e->device = net->gpu_index;
+    HIPCALL(y2h_set_device(e->device));
+    if (!e->stream) HIPCALL(y2h_stream_create(&e->stream));
+    free_plan(net);
+
+    /* every layer follows the network batch (set_batch_network only rewrites the field) */
+    for (i = 0; i < net->n; ++i) net->layers[i].batch = net->batch;
+
+    /* pass 1: let the sources of concatenating routes write into the route buffer */
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        y2_ldev *d = ld_of(l);
+        if (l->type == ROUTE && l->n == 1) d->alias_of = l->input_layers[0];
+        if (l->type == COST) d->alias_of = i - 1;
+        if (l->type != ROUTE || l->n < 2) continue;
+        if (l->n > 32) { y2_fail("route layer %d has %d inputs (max 32)", i, l->n); return -1; }
+        if (!l->out_c) { y2_fail("route layer %d concatenates layers of different spatial size", i); return -1; }
+        for (k = 0; k < l->n; ++k) {
+            layer *src = &net->layers[l->input_layers[k]];
+            y2_ldev *sd = ld_of(src);
+            int dup = 0, m;
+            for (m = 0; m < k; ++m) if (l->input_layers[m] == l->input_layers[k]) dup = 1;
+            if (!dup && producer_can_place(src) && sd->placed_in < 0 && l->input_layers[k] != e->out_layer)
+                sd->placed_in = i;
+            else
+                d->copy_mask |= 1u << k;
+        }
+    }
+    /* pass 2: allocate.  Routes first (their sources point into them). */
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        y2_ldev *d = ld_of(l);
+        if (l->type == ROUTE && l->n >= 2) {
+            d->out_floats = (size_t)l->batch * l->out_h * l->out_w * l->out_c;
+            HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * sizeof(float)));
+            d->out = d->out_alloc;
+            d->out_ld = l->out_c;
+        }
+    }
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        y2_ldev *d = ld_of(l);
+        switch (l->type) {
+        case CONVOLUTIONAL: case MAXPOOL: case REORG:
+            if (d->placed_in >= 0) {
+                layer *r = &net->layers[d->placed_in];
+                y2_ldev *rd = ld_of(r);
+                int choff = 0;
+                for (k = 0; k < r->n && r->input_layers[k] != i; ++k) choff += net->layers[r->input_layers[k]].out_c;
+                d->out = rd->out + choff;
+                d->out_ld = r->out_c;
+            } else {
+                d->out_floats = (size_t)l->batch * l->out_h * l->out_w * l->out_c;
+                HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * sizeof(float)));
+                d->out = d->out_alloc;
+                d->out_ld = l->out_c;
+            }
+            d->kernel = l->type == MAXPOOL ? "maxpool_nhwc" : (l->type == REORG ? "reorg_nhwc" : "conv");
+            break;
+        case ROUTE:
+            d->kernel = "route(zero-copy)";
+            if (l->n == 1) { y2_ldev *sd = ld_of(&net->layers[d->alias_of]); d->out = sd->out; d->out_ld = sd->out_ld; }
+            else if (d->copy_mask) d->kernel = "route(copy_channels)";
+            break;
+        case COST: {
+            y2_ldev *sd = ld_of(&net->layers[i - 1]);
+            d->out = sd->out; d->out_ld = sd->out_ld; d->kernel = "none";
+        } break;
+        case REGION:
+            HIPCALL(y2h_malloc((void **)&d->d_region, (size_t)l->batch * l->outputs * sizeof(float)));
+            d->out = d->d_region; d->out_ld = l->outputs / (l->h * l->w);
+            d->kernel = l->softmax_tree ? "region+tree_softmax" : "region";
+            break;
+        case AVGPOOL: case SOFTMAX:
+            HIPCALL(y2h_malloc((void **)&d->d_flat, (size_t)l->batch * l->outputs * sizeof(float)));
+            d->out = d->d_flat; d->out_ld = l->outputs;
+            d->kernel = l->type == AVGPOOL ? "avgpool" : "softmax_rows";
+            break;
+        default:
+            y2_fail("layer %d: type %d has no device implementation", i, (int)l->type);
+            return -1;
+        }
+    }
+    /* io */
+    e->in_floats = (size_t)net->batch * net->inputs;
+    HIPCALL(y2h_malloc((void **)&e->d_in_nchw, e->in_floats * sizeof(float)));
+    HIPCALL(y2h_malloc((void **)&e->d_in_nhwc, e->in_floats * sizeof(float)));
+    {
+        layer *ol = &net->layers[e->out_layer];
+        e->out_floats = (size_t)net->batch * ol->outputs;
+        HIPCALL(y2h_host_alloc((void **)&e->h_out, e->out_floats * sizeof(float)));
+        HIPCALL(y2h_malloc((void **)&e->d_out_nchw, e->out_floats * sizeof(float)));
+        ol->output = e->h_out;
+        if (ol->type == REGION) {
+            e->det_total = ol->w * ol->h * ol->n;
+            e->det_classes = ol->classes;
+            e->det_batch = net->batch;
+            e->det_cap = e->det_total;
+            HIPCALL(y2h_malloc((void **)&e->d_boxes, (size_t)net->batch * e->det_total * 4 * sizeof(float)));
+            HIPCALL(y2h_malloc((void **)&e->d_probs, (size_t)net->batch * e->det_total * ol->classes * sizeof(float)));
+            HIPCALL(y2h_malloc((void **)&e->d_records, (size_t)net->batch * e->det_cap * 6 * sizeof(float)));
+            HIPCALL(y2h_malloc((void **)&e->d_counts, (size_t)net->batch * sizeof(int)));
+            HIPCALL(y2h_host_alloc((void **)&e->h_records, (size_t)net->batch * e->det_cap * 6 * sizeof(float)));
+            HIPCALL(y2h_host_alloc((void **)&e->h_counts, (size_t)net->batch * sizeof(int)));
+        }
+    }
+    /* region constants */
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        y2_ldev *d = ld_of(l);
+        if (l->type != REGION) continue;
+        if (upload_small((void **)&d->d_anchors, l->biases, 2 * l->n * sizeof(float), e->stream)) { y2_fail("anchor upload: %s", y2h_last_error()); return -1; }
+        if (l->softmax_tree) {
+            tree *t = l->softmax_tree;
+            if (upload_small((void **)&d->d_tree_parent, t->parent, t->n * sizeof(int), e->stream) ||
+                upload_small((void **)&d->d_tree_gsize, t->group_size, t->groups * sizeof(int), e->stream) ||
+                upload_small((void **)&d->d_tree_goff, t->group_offset, t->groups * sizeof(int), e->stream)) {
+                y2_fail("tree upload: %s", y2h_last_error());
+                return -1;
+            }
+        }
+        if (l->map && upload_small((void **)&d->d_map, l->map, 200 * sizeof(int), e->stream)) { y2_fail("map upload: %s", y2h_last_error()); return -1; }
+    }
+    /* weight arena: decide per conv whether it runs on the matrix cores, then lay the arena out */
+    off = 0;
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        y2_ldev *d = ld_of(l);
+        y2h_conv c;
+        const float *x; int ldx;
+        size_t wbytes;
+        if (l->type != CONVOLUTIONAL) continue;
+        if (l->activation != LINEAR && l->activation != LEAKY && l->activation != LOGISTIC && l->activation != RELU) {
+            y2_fail("layer %d: activation %d is not implemented on the device", i, (int)l->activation);
+            return -1;
+        }
+        wbytes = (size_t)l->n * l->size * l->size * l->c * sizeof(float);
+        input_view(net, i, &x, &ldx);
+        conv_desc(net, i, &c, x, ldx);
+        c.w_packed = (const float *)(uintptr_t)256;       /* alignment stand-in for the query */
+        d->uses_mfma = !e->strict && y2h_conv_uses_mfma(&c);
+        d->has_w_ref = !d->uses_mfma;
+        d->off_w_packed = off; off = align_up(off + wbytes, 256);
+        if (d->has_w_ref) { d->off_w_ref = off; off = align_up(off + wbytes, 256); }
+        d->off_bias = off; off = align_up(off + l->n * sizeof(float), 64);
+        if (l->batch_normalize) {
+            d->off_mean = off; off = align_up(off + l->n * sizeof(float), 64);
+            d->off_scale = off; off = align_up(off + l->n * sizeof(float), 64);
+            d->off_rinv = off; off = align_up(off + l->n * sizeof(double), 64);
+        }
+        d->kernel = y2h_conv_variant(&c, e->strict);
+    }
+    if (off != e->arena_bytes || !e->arena) {
+        if (e->arena) y2h_free(e->arena);
+        e->arena = NULL;
+        e->arena_bytes = off;
+        HIPCALL(y2h_malloc((void **)&e->arena, off));
+        if (!e->weights_external) e->weights_dirty = 1;
+    }
+    if (e->built_strict != e->strict) e->weights_dirty = e->weights_external ? e->weights_dirty : 1;
+    /* timing events */
+    if (e->n_ev != net->n + 1) {
+        if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
+        e->n_ev = net->n + 1;
+        e->ev = calloc(e->n_ev, sizeof(y2h_event));
+        for (i = 0; i < e->n_ev; ++i) HIPCALL(y2h_event_create(&e->ev[i]));
+    }
+    e->built = 1;
+    e->built_batch = net->batch; e->built_w = net->w; e->built_h = net->h; e->built_strict = e->strict;
+    if (e->weights_dirty && !e->weights_external && upload_weights(net) != 0) return -1;
+    return 0;
+}
+
+static int ensure_built(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (!e) { y2_fail("network has no engine (was it built by parse_network_cfg?)"); return -1; }
+    if (!e->built || e->built_batch != net->batch || e->built_w != net->w || e->built_h != net->h ||
+        e->built_strict != e->strict) {
+        if (y2_engine_build(net) != 0) return -1;
+    } else {
+        HIPCALL(y2h_set_device(e->device));
+        if (e->weights_dirty && !e->weights_external && upload_weights(net) != 0) return -1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* forward                                                             */
+/* ------------------------------------------------------------------ */
+int y2_engine_forward(network *net, const float *d_input_nchw)
+{
+    y2_engine *e;
+    int i, k;
+    if (ensure_built(net) != 0) return -1;
+    e = y2_engine_of(net);
+    if (net->c <= 0 || net->h <= 0 || net->w <= 0) { y2_fail("network input must be an image (h,w,c > 0)"); return -1; }
+    HIPCALL(y2h_nchw_to_nhwc(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));
+    if (e->timing) HIPCALL(y2h_event_record(e->ev[0], e->stream));
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        y2_ldev *d = ld_of(l);
+        const float *x; int ldx;
+        input_view(net, i, &x, &ldx);
+        switch (l->type) {
+        case CONVOLUTIONAL: {
+            y2h_conv c;
+            conv_desc(net, i, &c, x, ldx);
+            HIPCALL(y2h_conv_forward(&c, e->strict, e->stream));
+        } break;
+        case MAXPOOL:
+            HIPCALL(y2h_maxpool(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->size, l->stride, l->pad,
+                                l->out_h, l->out_w, e->stream));
+            break;
+        case REORG:
+            HIPCALL(y2h_reorg(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->stride, l->reverse, e->stream));
+            break;
+        case ROUTE:
+            if (l->n >= 2 && d->copy_mask) {
+                int choff = 0;
+                for (k = 0; k < l->n; ++k) {
+                    layer *src = &net->layers[l->input_layers[k]];
+                    y2_ldev *sd = ld_of(src);
+                    if (d->copy_mask & (1u << k))
+                        HIPCALL(y2h_copy_channels(sd->out, sd->out_ld, d->out + choff, d->out_ld, src->out_c,
+                                                  (long)l->batch * l->out_h * l->out_w, e->stream));
+                    choff += src->out_c;
+                }
+            }
+            break;
+        case REGION: {
+            tree *t = l->softmax_tree;
+            HIPCALL(y2h_region_forward(x, ldx, d->d_region, l->batch, l->h * l->w, l->n, l->classes, l->coords, l->softmax,
+                                       t ? t->groups : 0, d->d_tree_gsize, d->d_tree_goff, e->stream));
+        } break;
+        case AVGPOOL:
+            HIPCALL(y2h_avgpool(x, ldx, d->d_flat, l->batch, l->h, l->w, l->c, e->stream));
+            break;
+        case SOFTMAX: {
+            /* the input of a softmax layer is a flat [batch][inputs] vector; an image-like producer
+             * (1x1 spatial, as after avgpool) is contiguous when its stride equals its channel count */
+            layer *pl = &net->layers[i - 1];
+            if (i == 0 || (pl->out_h * pl->out_w > 1 && pl->type != AVGPOOL && pl->type != SOFTMAX)) {
+                y2_fail("softmax layer %d: input must be a flat vector (e.g. after avgpool)", i);
+                return -1;
+            }
+            if (l->softmax_tree) { y2_fail("softmax layer with tree= is not implemented on the device"); return -1; }
+            HIPCALL(y2h_softmax_rows(x, d->d_flat, (long)l->batch * l->groups, l->inputs / l->groups, l->temperature, e->stream));
+        } break;
+        case COST:
+            break;                    /* cost_layer.c:75: nothing happens without truth */
+        default:
+            y2_fail("layer %d: unsupported type", i);
+            return -1;
+        }
+        if (e->timing) HIPCALL(y2h_event_record(e->ev[i + 1], e->stream));
+    }
+    return 0;
+}
+
+/* copy the output layer to the pinned host buffer in the reference's layout */
+int y2_engine_fetch_output(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    layer *l = &net->layers[e->out_layer];
+    y2_ldev *d = ld_of(l);
+    const float *src;
+    if (l->type == REGION || l->type == AVGPOOL || l->type == SOFTMAX) src = d->out;
+    else {
+        HIPCALL(y2h_nhwc_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
+        src = e->d_out_nchw;
+    }
+    HIPCALL(y2h_memcpy_d2h(e->h_out, src, e->out_floats * sizeof(float), e->stream));
+    HIPCALL(y2h_stream_sync(e->stream));
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* public runtime API                                                  */
+/* ------------------------------------------------------------------ */
+void cuda_set_device(int n)                  /* cuda.c:12-17 */
+{
+    gpu_index = n;
+    if (n >= 0 && y2h_set_device(n) != 0) y2_fail("cuda_set_device(%d): %s", n, y2h_last_error());
+}
+
+float *network_predict(network net, float *input)
+{
+    y2_engine *e;
+    if (ensure_built(&net) != 0) return NULL;
+    e = y2_engine_of(&net);
+    if (y2h_memcpy_h2d(e->d_in_nchw, input, e->in_floats * sizeof(float), e->stream) != 0) {
+        y2_fail("input upload: %s", y2h_last_error());
+        return NULL;
+    }
+    if (y2_engine_forward(&net, e->d_in_nchw) != 0) return NULL;
+    if (y2_engine_fetch_output(&net) != 0) return NULL;
+    return e->h_out;
+}
+
+float *network_predict_gpu(network net, float *input) { return network_predict(net, input); }
+
+float *y2_network_predict_device(network net, const float *d_input)
+{
+    if (y2_engine_forward(&net, d_input) != 0) return NULL;
+    if (y2_engine_fetch_output(&net) != 0) return NULL;
+    return y2_engine_of(&net)->h_out;
+}
+
+int y2_forward_device(network net, const float *d_input) { return y2_engine_forward(&net, d_input); }
+
+int y2_prepare(network *net) { return ensure_built(net); }
+
+void y2_set_strict(network *net, int strict)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (e) e->strict = strict ? 1 : 0;
+}
+
+void y2_set_timing(network *net, int on)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (e) e->timing = on ? 1 : 0;
+}
+
+int y2_layer_times_ms(network net, float *ms, int max_layers)
+{
+    y2_engine *e = y2_engine_of(&net);
+    int i, n;
+    if (!e || !e->built || !e->timing) return 0;
+    n = net.n < max_layers ? net.n : max_layers;
+    for (i = 0; i < n; ++i) if (y2h_event_elapsed_ms(e->ev[i], e->ev[i + 1], &ms[i]) != 0) return i;
+    return n;
+}
+
+const char *y2_layer_kernel(network net, int i)
+{
+    if (i < 0 || i >= net.n || !net.layers[i].dev) return "";
+    return ld_of(&net.layers[i])->kernel ? ld_of(&net.layers[i])->kernel : "";
+}
+
+int y2_weights_arena(network *net, void **dev_ptr, size_t *bytes)
+{
+    y2_engine *e;
+    int keep;
+    if (!y2_engine_of(net)) return -1;
+    e = y2_engine_of(net);
+    /* building must not try to upload host weights that were never loaded */
+    keep = e->weights_dirty;
+    if (!e->built) { e->weights_external = 1; if (y2_engine_build(net) != 0) return -1; e->weights_external = 0; e->weights_dirty = keep; }
+    if (dev_ptr) *dev_ptr = e->arena;
+    if (bytes) *bytes = e->arena_bytes;
+    return 0;
+}
+
+void y2_weights_resident(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (e) { e->weights_external = 1; e->weights_dirty = 0; }
+}
+
+void *y2_stream(network net) { y2_engine *e = y2_engine_of(&net); return e ? e->stream : NULL; }
+void y2_sync(network net) { y2_engine *e = y2_engine_of(&net); if (e && e->stream) y2h_stream_sync(e->stream); }
+
+int y2_pull_layer_output(network net, int i, float *dst)
+{
+    y2_engine *e = y2_engine_of(&net);
+    layer *l;
+    y2_ldev *d;
+    float *tmp = NULL;
+    size_t n;
+    if (!e || !e->built || i < 0 || i >= net.n) { y2_fail("y2_pull_layer_output: no forward has run"); return -1; }
+    l = &net.layers[i];
+    d = ld_of(l);
+    n = (size_t)l->batch * l->outputs;
+    HIPCALL(y2h_set_device(e->device));
+    if (l->type == REGION || l->type == AVGPOOL || l->type == SOFTMAX || (l->type == COST && (l->out_h == 0 || l->out_w == 0))) {
+        HIPCALL(y2h_memcpy_d2h(dst, d->out, n * sizeof(float), e->stream));
+        HIPCALL(y2h_stream_sync(e->stream));
+        return 0;
+    }
+    HIPCALL(y2h_malloc((void **)&tmp, n * sizeof(float)));
+    if (y2h_nhwc_to_nchw(d->out, d->out_ld, tmp, l->batch, l->out_c, l->out_h, l->out_w, e->stream) != 0 ||
+        y2h_memcpy_d2h(dst, tmp, n * sizeof(float), e->stream) != 0 || y2h_stream_sync(e->stream) != 0) {
+        y2h_free(tmp);
+        y2_fail("y2_pull_layer_output: %s", y2h_last_error());
+        return -1;
+    }
+    y2h_free(tmp);
+    return 0;
+}
+
+float *get_network_output(network net)       /* network.c:173-181 */
+{
+    int i = y2_out_layer(&net);
+    return net.layers[i].output;
+}
+float *get_network_output_gpu(network net) { return get_network_output(net); }
+int get_network_output_size(network net) { return net.layers[y2_out_layer(&net)].outputs; }
+int get_network_input_size(network net) { return net.layers[0].inputs; }
+
+void set_batch_network(network *net, int b)  /* network.c:308-320 */
+{
+    int i;
+    if (b <= 0) { y2_fail("set_batch_network: batch %d", b); return; }
+    net->batch = b;
+    for (i = 0; i < net->n; ++i) net->layers[i].batch = b;
+    /* buffers are re-planned at the next predict if the batch changed */
+}
+
+int resize_network(network *net, int w, int h)   /* network.c:322-388 */
+{
+    int i, inputs = 0, k;
+    net->w = w; net->h = h;
+    net->inputs = w * h * net->c;
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        switch (l->type) {
+        case CONVOLUTIONAL:                  /* convolutional_layer.c:360-398 */
+            l->w = w; l->h = h;
+            l->out_w = (l->w + 2 * l->pad - l->size) / l->stride + 1;
+            l->out_h = (l->h + 2 * l->pad - l->size) / l->stride + 1;
+            l->outputs = l->out_h * l->out_w * l->out_c;
+            l->inputs = l->w * l->h * l->c;
+            l->workspace_size = (size_t)l->out_h * l->out_w * l->size * l->size * l->c * sizeof(float);
+            break;
+        case MAXPOOL:                        /* maxpool_layer.c:54-77 */
+            l->w = w; l->h = h;
+            l->inputs = h * w * l->c;
+            l->out_w = (w + 2 * l->pad) / l->stride;
+            l->out_h = (h + 2 * l->pad) / l->stride;
+            l->outputs = l->out_w * l->out_h * l->c;
+            break;
+        case REGION:                         /* region_layer.c:53-71 */
+            l->w = w; l->h = h;
+            l->outputs = h * w * l->n * (l->classes + l->coords + 1);
+            l->inputs = l->outputs;
+            break;
+        case ROUTE: {                        /* route_layer.c:39-71 */
+            layer *first = &net->layers[l->input_layers[0]];
+            l->out_w = first->out_w; l->out_h = first->out_h; l->out_c = first->out_c;
+            l->outputs = first->outputs;
+            l->input_sizes[0] = first->outputs;
+            for (k = 1; k < l->n; ++k) {
+                layer *nx = &net->layers[l->input_layers[k]];
+                l->outputs += nx->outputs;
+                l->input_sizes[k] = nx->outputs;
+                if (nx->out_w == first->out_w && nx->out_h == first->out_h) l->out_c += nx->out_c;
+                else l->out_h = l->out_w = l->out_c = 0;
+            }
+            l->inputs = l->outputs;
+            l->h = l->out_h; l->w = l->out_w; l->c = l->out_c;
+        } break;
+        case REORG:                          /* reorg_layer.c:45-76 */
+            l->w = w; l->h = h;
+            if (l->reverse) { l->out_w = w * l->stride; l->out_h = h * l->stride; l->out_c = l->c / (l->stride * l->stride); }
+            else { l->out_w = w / l->stride; l->out_h = h / l->stride; l->out_c = l->c * (l->stride * l->stride); }
+            l->outputs = l->out_h * l->out_w * l->out_c;
+            l->inputs = l->outputs;
+            break;
+        case AVGPOOL:                        /* avgpool_layer.c:33-38 */
+            l->w = w; l->h = h;
+            l->inputs = h * w * l->c;
+            break;
+        case COST: case SOFTMAX:
+            l->inputs = inputs; l->outputs = inputs;
+            break;
+        default:
+            fprintf(stderr, "Resizing type %d \n", (int)l->type);
+            y2_fail("Cannot resize this type of layer");
+            return -1;
+        }
+        inputs = l->outputs;
+        w = l->out_w; h = l->out_h;
+        if (l->type == AVGPOOL) break;       /* network.c:366: layers after avgpool keep their size */
+    }
+    net->outputs = net->layers[y2_out_layer(net)].outputs;
+    y2_engine_invalidate(net);
+    return 0;
+}
+
+static void free_tree(tree *t)
+{
+    int i;
+    if (!t) return;
+    if (t->name) for (i = 0; i < t->n; ++i) free(t->name[i]);
+    free(t->name); free(t->leaf); free(t->parent); free(t->group); free(t->group_size); free(t->group_offset);
+    free(t);
+}
+
+void free_network(network net)               /* network.c:592-609 */
+{
+    int i;
+    if (!net.layers) return;
+    y2_engine_destroy(&net);
+    for (i = 0; i < net.n; ++i) {
+        layer *l = &net.layers[i];
+        free(l->weights); free(l->biases); free(l->scales); free(l->rolling_mean); free(l->rolling_variance);
+        free(l->input_layers); free(l->input_sizes); free(l->map); free(l->cost);
+        free_tree(l->softmax_tree);
+    }
+    free(net.layers);
+    free(net.seen);
+}
+
+void top_predictions(network net, int k, int *index)   /* network.c:449-454 */
+{
+    top_k(get_network_output(net), get_network_output_size(net), k, index);
+}
+
+char *get_layer_string(LAYER_TYPE a)         /* network.c:73-130 */
+{
+    switch (a) {
+    case CONVOLUTIONAL: return "convolutional";
+    case MAXPOOL: return "maxpool";
+    case ROUTE: return "route";
+    case REORG: return "reorg";
+    case REGION: return "region";
+    case AVGPOOL: return "avgpool";
+    case SOFTMAX: return "softmax";
+    case COST: return "cost";
+    default: return "none";
+    }
+}

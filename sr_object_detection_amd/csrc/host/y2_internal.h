@@ -1,0 +1,87 @@
+/* Internal declarations shared by the host C sources of libsr_yolo2.so. */
+#ifndef Y2_INTERNAL_H
+#define Y2_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "sr_yolo2.h"
+#include "y2_hip.h"
+
+/* per-layer device-side state (layer.dev) */
+typedef struct y2_ldev {
+    struct y2_engine *eng;
+    int index;
+    /* where this layer's activations live: NHWC, `ld` floats between pixels */
+    float *out;
+    int out_ld;
+    float *out_alloc;          /* allocation owned by this layer, NULL when the output sits in another buffer */
+    size_t out_floats;
+    int placed_in;             /* index of the [route] layer whose buffer holds this output, or -1 */
+    int alias_of;              /* [route] with one input / [cost]: index of the layer whose output is reused, or -1 */
+    unsigned copy_mask;        /* [route]: bit k set -> input k needs a copy kernel (could not be placed) */
+    /* convolution parameters inside the weight arena */
+    size_t off_w_packed, off_w_ref, off_bias, off_mean, off_scale, off_rinv;
+    int has_w_ref;
+    int uses_mfma;
+    /* region */
+    float *d_anchors;
+    int *d_tree_parent, *d_tree_gsize, *d_tree_goff, *d_map;
+    float *d_region;           /* [batch][outputs] flattened region output */
+    /* classifier tail */
+    float *d_flat;             /* avgpool / softmax output [batch][outputs] */
+    const char *kernel;        /* name for profiles */
+} y2_ldev;
+
+typedef struct y2_engine {
+    int device;
+    y2h_stream stream;
+    int strict;
+    int timing;
+    /* plan state */
+    int built;
+    int built_batch, built_w, built_h, built_strict;
+    int weights_dirty;         /* host weights changed since the last upload */
+    int weights_external;      /* arena filled from outside (broadcast) */
+    /* weight arena */
+    unsigned char *arena;
+    size_t arena_bytes;
+    /* io buffers */
+    float *d_in_nchw, *d_in_nhwc;
+    size_t in_floats;
+    float *d_out_nchw;         /* staging when the output layer is image-like */
+    float *h_out;              /* pinned; what network_predict returns */
+    size_t out_floats;
+    int out_layer;
+    /* decode / nms buffers for the output region layer */
+    float *d_boxes, *d_probs, *d_records;
+    int *d_counts;
+    float *h_records;
+    int *h_counts;
+    int det_cap;               /* records per image */
+    int det_batch, det_total, det_classes;
+    /* timing */
+    y2h_event *ev;             /* n+1 events */
+    int n_ev;
+    int n_layers;
+} y2_engine;
+
+/* error handling: mode 0 = the reference's contract (message + exit), 1 = record and return */
+void y2_fail(const char *fmt, ...);
+int y2_error_mode(void);
+int y2_failed(void);           /* and clear */
+
+/* engine */
+y2_engine *y2_engine_of(const network *net);
+int y2_engine_create(network *net);
+void y2_engine_destroy(network *net);
+void y2_engine_invalidate(network *net);
+int y2_engine_build(network *net);
+int y2_engine_forward(network *net, const float *d_input_nchw);
+int y2_engine_fetch_output(network *net);
+
+/* cfg helpers shared with other files */
+char *y2_fgetl(FILE *fp);
+void y2_strip(char *s);
+int y2_out_layer(const network *net);
+
+#endif

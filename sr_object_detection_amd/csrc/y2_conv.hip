@@ -1,0 +1,383 @@
+// Convolution + fused batch-norm / bias / activation epilogue for gfx950.
+//
+// Replaces, in ONE launch per layer, the reference's GPU sequence
+//   fill_ongpu -> per image { im2col_ongpu ; gemm_ongpu } -> normalize_gpu ->
+//   scale_bias_gpu -> add_bias_gpu -> activate_array_ongpu
+// (src_yolo2/convolutional_kernels.cu:77-131, batchnorm_layer.c:194-197), whose
+// CPU semantics are convolutional_layer.c:435-474 + blas.c:115-126.
+//
+// Two kernels:
+//
+//  * conv_mfma_kernel -- implicit GEMM on the fp32 matrix cores
+//    (v_mfma_f32_32x32x2_f32).  out[pixel][cout] = sum_k patch[pixel][k] *
+//    W[cout][k], with the GEMM "M" dimension = B*H*W output pixels (NHWC, so
+//    a pixel's channels are contiguous), "N" = filters and
+//    k = (kh*size + kw)*Cin + ci.  No im2col buffer exists: each K-step
+//    stages a [BM pixels][BK channels] slice of one filter tap straight from
+//    the NHWC input (one 128-byte line per pixel, zero for padding taps via
+//    the buffer-load range check) and a [BN filters][BK] slice of the packed
+//    weights into LDS, double buffered, while the previous slice is consumed
+//    by MFMAs.  LDS rows are padded to BK+4 floats so the ds_read_b128 fragment
+//    reads (one per 4 MFMA k-steps) are bank-conflict free.
+//    The MFMA is an exact k-ordered fp32 fma chain, so results differ from the
+//    CPU path (separately rounded mul+add, ci-major k order) only by ordinary
+//    fp32 summation noise (~1e-6 relative).
+//
+//  * conv_direct_kernel -- plain VALU kernel for shapes the MFMA kernel does
+//    not take (Cin=3 first layer, odd strides/sizes) and for the strict mode:
+//    it accumulates in the reference's exact order (ci, kh, kw ascending;
+//    product and sum rounded separately, gemm.c:74-88) and is bit-identical to
+//    the CPU path.
+//
+// The epilogue reproduces blas.c:122 / convolutional_layer.c:407-419 /
+// activations.h:41 step by step, each step rounded to fp32 as the reference's
+// separate passes do: (x - mean) * [1/(sqrt((double)var)+1e-6f)] in double,
+// * scale, + bias, leaky as .1*x in double.
+//
+// This file is compiled with -ffp-contract=off: no mul+add below may fuse.
+#include "y2_common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvK {
+    const float *x;
+    const float *w;
+    float *y;
+    const float *mean;
+    const double *rinv;
+    const float *scale;
+    const float *bias;
+    int H, W, Cin, ldx, Cout, ldy, K;
+    int npix;          // batch * H * W (output pixels == input pixels for the MFMA path)
+    int bn, act;
+    unsigned xbytes, wbytes;
+    int tiles_n;
+    // direct kernel only
+    int size, stride, pad, out_h, out_w, batch;
+};
+
+__device__ __forceinline__ float epilogue(float v, bool bn, float mean, double rinv, float scale, float bias, int act)
+{
+    if (bn) {
+        float d = v - mean;                 // blas.c:122 numerator, fp32
+        v = (float)((double)d * rinv);      // divide by (sqrt(var)+1e-6f) evaluated in double
+        v = v * scale;                      // convolutional_layer.c:419
+    }
+    v = v + bias;                           // convolutional_layer.c:407
+    if (act == Y2H_ACT_LEAKY) v = (v > 0) ? v : (float)(.1 * (double)v);              // activations.h:41
+    else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));       // activations.h:35
+    else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);                             // activations.h:37
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// MFMA implicit GEMM
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int BK, int KS, int WM, int WN>
+__global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
+{
+    constexpr int NT = WM * WN * 64;
+    constexpr int LS = BK + 4;            // LDS row stride (floats); (LS/4) odd -> conflict-free b128 reads
+    constexpr int CH = BK / 4;            // 16-byte chunks per staged row
+    constexpr int RP = NT / CH;           // rows staged per pass
+    constexpr int PA = (BM + RP - 1) / RP, PB = (BN + RP - 1) / RP;   // staging passes (last may be partial)
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // [2 buffers][BM + BN rows][LS]
+    constexpr int BUF = (BM + BN) * LS;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int bid = blockIdx.x;
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int p0 = tile_m * BM, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+
+    // staging role of this thread: chunk `sc` of rows `sr + q*RP`
+    const int sc = t % CH, sr = t / CH;
+    unsigned a_off[PA];      // byte offset of the pixel's channel 0 (+ this thread's chunk)
+    unsigned a_msk[PA];      // validity of the KS*KS taps
+    const int HW = a.H * a.W;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+        const int p = p0 + sr + q * RP;
+        const int rem = p % HW;
+        const int py = rem / a.W, px = rem - py * a.W;
+        a_off[q] = ((unsigned)p * (unsigned)a.ldx + (unsigned)sc * 4u) * 4u;
+        unsigned m = 0;
+        if (p < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
+            if (KS == 1) m = 1u;
+            else {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int yy = py + kh - 1, xx = px + kw - 1;
+                        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) m |= 1u << (kh * 3 + kw);
+                    }
+            }
+        }
+        a_msk[q] = m;
+    }
+    unsigned b_off[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const unsigned co = (unsigned)(n0 + sr + q * RP);
+        // rows past Cout (or past the tile) land beyond wbytes and read as zero
+        b_off[q] = (co < (unsigned)a.Cout && sr + q * RP < BN) ? (co * (unsigned)a.K + (unsigned)sc * 4u) * 4u : a.wbytes;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = KS * KS * (a.Cin / BK);
+    f32x4 ra[PA], rb[PB];
+
+    int tap = 0, c0 = 0;      // position of the NEXT slice to load
+    auto load_slice = [&]() {
+        int delta = 0;        // float offset of the tap relative to the centre pixel
+        if (KS == 3) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            delta = ((kh - 1) * a.W + (kw - 1)) * a.ldx;
+        }
+        const unsigned add = (unsigned)((delta + c0) * 4);
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const bool ok = (a_msk[q] >> tap) & 1u;
+            const unsigned off = ok ? a_off[q] + add : a.xbytes;
+            ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+        }
+        const unsigned kadd = (unsigned)((tap * a.Cin + c0) * 4);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const unsigned off = (b_off[q] == a.wbytes) ? a.wbytes : b_off[q] + kadd;
+            rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+        }
+        c0 += BK;
+        if (c0 == a.Cin) { c0 = 0; ++tap; }
+    };
+    auto store_slice = [&](int buf) {
+        float *As = smem + buf * BUF;
+        float *Bs = As + BM * LS;
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+            if (BM % RP == 0 || sr + q * RP < BM) *(f32x4 *)&As[(sr + q * RP) * LS + sc * 4] = ra[q];
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
+            if (BN % RP == 0 || sr + q * RP < BN) *(f32x4 *)&Bs[(sr + q * RP) * LS + sc * 4] = rb[q];
+    };
+
+    load_slice();
+    store_slice(0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) load_slice();                      // global loads in flight under the MFMAs
+        const float *As = smem + cur * BUF + (wm * (BM / WM) + li) * LS + lh * 4;
+        const float *Bs = smem + cur * BUF + BM * LS + (wn * (BN / WN) + li) * LS + lh * 4;
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4 *)&As[i * 32 * LS + kg * 8];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4 *)&Bs[j * 32 * LS + kg * 8];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_slice(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: lane holds column (cout) li of each 32x32 tile and 16 rows (pixels)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * (BN / WN) + j * 32 + li;
+        const bool cok = co < a.Cout;
+        float mean = 0.f, scale = 1.f, bias = 0.f;
+        double rinv = 1.0;
+        if (cok) {
+            bias = a.bias[co];
+            if (a.bn) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int prow = p0 + wm * (BM / WM) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = prow + (r & 3) + 8 * (r >> 2);
+                if (cok && p < a.npix)
+                    a.y[(size_t)p * a.ldy + co] = epilogue(acc[i][j][r], a.bn, mean, rinv, scale, bias, a.act);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// direct kernel (reference accumulation order; bit-identical to the CPU path)
+// weights in the reference's [n][c][kh][kw] layout
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvK a)
+{
+    const long total = (long)a.batch * a.out_h * a.out_w * a.Cout;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int co = (int)(idx % a.Cout);
+        const long op = idx / a.Cout;
+        const int ox = (int)(op % a.out_w);
+        const int oy = (int)((op / a.out_w) % a.out_h);
+        const int n = (int)(op / ((long)a.out_w * a.out_h));
+        const float *wrow = a.w + (size_t)co * a.K;
+        float sum = 0.f;
+        for (int c = 0; c < a.Cin; ++c)
+            for (int kh = 0; kh < a.size; ++kh) {
+                const int iy = oy * a.stride + kh - a.pad;
+                for (int kw = 0; kw < a.size; ++kw) {
+                    const int ix = ox * a.stride + kw - a.pad;
+                    float xv = 0.f;
+                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                        xv = a.x[((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + c];
+                    const float prod = wrow[(c * a.size + kh) * a.size + kw] * xv;
+                    sum = sum + prod;
+                }
+            }
+        float mean = 0.f, scale = 1.f;
+        double rinv = 1.0;
+        if (a.bn) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
+        a.y[(size_t)op * a.ldy + co] = epilogue(sum, a.bn, mean, rinv, scale, a.bias[co], a.act);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------
+struct Variant {
+    const char *name;
+    int bm, bn, bk, ks;
+    void (*fn)(ConvK);
+    size_t lds;
+    int threads;
+    bool attr_set[16];     // per device
+};
+
+#define VAR(BM, BN, BK, KS, WM, WN)                                                             \
+    { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN>, \
+      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float), WM * WN * 64, {false} }
+
+static Variant g_variants[] = {
+    VAR(128, 128, 32, 3, 2, 2), VAR(128, 128, 32, 1, 2, 2),
+    VAR(128, 64, 32, 3, 2, 2),  VAR(128, 64, 32, 1, 2, 2),
+    VAR(64, 64, 32, 3, 2, 2),   VAR(64, 64, 32, 1, 2, 2),
+    VAR(128, 32, 32, 3, 4, 1),  VAR(128, 32, 32, 1, 4, 1),
+    VAR(128, 128, 16, 3, 2, 2), VAR(128, 128, 16, 1, 2, 2),
+    VAR(128, 64, 16, 3, 2, 2),  VAR(128, 64, 16, 1, 2, 2),
+    VAR(64, 64, 16, 3, 2, 2),   VAR(64, 64, 16, 1, 2, 2),
+    VAR(128, 32, 16, 3, 4, 1),  VAR(128, 32, 16, 1, 4, 1),
+};
+
+static bool mfma_ok(const y2h_conv *d)
+{
+    if (!(d->size == 1 || d->size == 3)) return false;
+    if (d->stride != 1 || d->pad != d->size / 2) return false;
+    if (d->c % 16 != 0 || d->ldx % 4 != 0) return false;
+    if (d->out_h != d->h || d->out_w != d->w) return false;
+    if (((uintptr_t)d->x | (uintptr_t)d->w_packed) % 16 != 0) return false;
+    const double xbytes = (double)d->batch * d->h * d->w * d->ldx * 4.0;
+    const double wbytes = (double)d->n * d->size * d->size * d->c * 4.0;
+    if (xbytes >= 4294967000.0 || wbytes >= 4294967000.0) return false;   // 32-bit buffer offsets
+    return d->w_packed != nullptr;
+}
+
+static Variant *pick_variant(const y2h_conv *d)
+{
+    const int bk = (d->c % 32 == 0) ? 32 : 16;
+    const long npix = (long)d->batch * d->h * d->w;
+    int bn = d->n <= 32 ? 32 : (d->n <= 64 ? 64 : 128);
+    int bm = 128;
+    if (bn == 128) {
+        // small problems: prefer more, smaller blocks so that all 256 CUs get work
+        const long blocks = ((npix + 127) / 128) * ((d->n + 127) / 128);
+        if (blocks < 2 * 256) { bm = 64; bn = 64; }
+    } else if (bn == 64) {
+        const long blocks = ((npix + 127) / 128) * ((d->n + 63) / 64);
+        if (blocks < 2 * 256) bm = 64;
+    }
+    for (Variant &v : g_variants)
+        if (v.bm == bm && v.bn == bn && v.bk == bk && v.ks == d->size) return &v;
+    return nullptr;
+}
+
+extern "C" int y2h_conv_uses_mfma(const y2h_conv *d) { return mfma_ok(d) && pick_variant(d) ? 1 : 0; }
+
+extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
+{
+    if (!strict && mfma_ok(d)) {
+        Variant *v = pick_variant(d);
+        if (v) return v->name;
+    }
+    return "conv_direct_f32";
+}
+
+extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
+{
+    if (!d || !d->x || !d->y || !d->bias) return Y2H_EINVAL;
+    if (d->batch <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->n <= 0 || d->ldx < d->c || d->ldy < d->n) return Y2H_EINVAL;
+    if (d->batch_normalize && (!d->mean || !d->rinv || !d->scale)) return Y2H_EINVAL;
+    if (d->out_h != (d->h + 2 * d->pad - d->size) / d->stride + 1) return Y2H_EINVAL;
+    if (d->out_w != (d->w + 2 * d->pad - d->size) / d->stride + 1) return Y2H_EINVAL;
+
+    ConvK a;
+    memset(&a, 0, sizeof a);
+    a.x = d->x; a.y = d->y;
+    a.mean = d->mean; a.rinv = d->rinv; a.scale = d->scale; a.bias = d->bias;
+    a.H = d->h; a.W = d->w; a.Cin = d->c; a.ldx = d->ldx; a.Cout = d->n; a.ldy = d->ldy;
+    a.K = d->size * d->size * d->c;
+    a.bn = d->batch_normalize; a.act = d->activation;
+    a.size = d->size; a.stride = d->stride; a.pad = d->pad; a.out_h = d->out_h; a.out_w = d->out_w; a.batch = d->batch;
+
+    Variant *v = (!strict && mfma_ok(d)) ? pick_variant(d) : nullptr;
+    if (v) {
+        a.w = d->w_packed;
+        a.npix = d->batch * d->h * d->w;
+        a.xbytes = (unsigned)((size_t)d->batch * d->h * d->w * d->ldx * 4);
+        a.wbytes = (unsigned)((size_t)d->n * a.K * 4);
+        a.tiles_n = (d->n + v->bn - 1) / v->bn;
+        const long tiles_m = ((long)a.npix + v->bm - 1) / v->bm;
+        int dev = 0;
+        Y2H_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16 || !v->attr_set[dev]) {
+            Y2H_CHECK(hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
+            if (dev >= 0 && dev < 16) v->attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(v->fn, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(v->threads), v->lds, S(s), a);
+        Y2H_LAUNCH_CHECK();
+        return Y2H_OK;
+    }
+    if (!d->w_ref) return Y2H_EINVAL;     // direct kernel needs the reference-layout weights
+    a.w = d->w_ref;
+    const long total = (long)d->batch * d->out_h * d->out_w * d->n;
+    hipLaunchKernelGGL(conv_direct_kernel, dim3(y2h_grid(total, 256, 256 * 32)), dim3(256), 0, S(s), a);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

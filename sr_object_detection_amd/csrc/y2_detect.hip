@@ -1,0 +1,399 @@
+// Box decode, non-maximum suppression and detection hand-off on the device
+// (include/y2_hip.h).  In the reference these run on the CPU in both builds
+// (src_yolo2/region_layer.c:328-379, src_yolo2/box.c:239-298,
+// src_yolo2/yolo_v2_class.cpp:221-238); here they are kernels so a frame batch
+// never leaves HBM until the compact detection records do.
+//
+// Every float expression mirrors the reference's C expression (same operand
+// types, same order) and the file is compiled with -ffp-contract=off, so given
+// the same region-layer tensor the boxes, probabilities and NMS decisions are
+// bit-identical to the CPU path.
+#include "y2_common.hpp"
+#include <float.h>
+
+// ---------------------------------------------------------------------------
+// get_region_boxes (region_layer.c:328-379) + get_region_box (:73-85, DOABS=1)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float logistic_f(float x) { return (float)(1. / (1. + exp(-(double)x))); }
+
+struct DecodeK {
+    int w, h, num, classes, img_w, img_h;
+    float thresh;
+    int only_objectness, classfix;
+    const float *anchors;
+    const int *parent;
+    const int *map;
+    float *pred;
+    float *boxes;
+    float *probs;
+    long nboxes;       // batch * w * h * num
+};
+
+__global__ __launch_bounds__(64) void decode_boxes_kernel(DecodeK d)
+{
+    const long gi = (long)blockIdx.x * 64 + threadIdx.x;
+    if (gi >= d.nboxes) return;
+    const int total = d.w * d.h * d.num;
+    const int index = (int)(gi % total);             // box index inside its image
+    const int n = index % d.num;
+    const int cell = index / d.num;
+    const int row = cell / d.w, col = cell % d.w;
+    const int size = d.classes + 5;
+    float *x = d.pred + gi * size;
+    float scale = x[4];
+    if (d.classfix == -1 && scale < .5) scale = 0;
+    float bx = (col + logistic_f(x[0])) / d.w;
+    float by = (row + logistic_f(x[1])) / d.h;
+    float bw = (float)(exp((double)x[2]) * d.anchors[2 * n] / d.w);
+    float bh = (float)(exp((double)x[3]) * d.anchors[2 * n + 1] / d.h);
+    bx *= d.img_w; by *= d.img_h; bw *= d.img_w; bh *= d.img_h;
+    float *bo = d.boxes + gi * 4;
+    bo[0] = bx; bo[1] = by; bo[2] = bw; bo[3] = bh;
+    float *pr = d.probs + gi * d.classes;
+    if (d.parent) {
+        // tree.c:37-44 hierarchy_predictions: parents precede children, in place
+        float *p = x + 5;
+        for (int j = 0; j < d.classes; ++j) {
+            const int par = d.parent[j];
+            if (par >= 0) p[j] *= p[par];
+        }
+        if (d.map) {
+            for (int j = 0; j < 200; ++j) {
+                const float prob = scale * p[d.map[j]];
+                pr[j] = (prob > d.thresh) ? prob : 0;
+            }
+        } else {
+            int found = 0;
+            for (int j = d.classes - 1; j >= 0; --j) {
+                if (!found && p[j] > .5) found = 1;
+                else p[j] = 0;
+                const float prob = p[j];
+                pr[j] = (scale > d.thresh) ? prob : 0;
+            }
+        }
+        if (d.only_objectness) pr[0] = scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void decode_probs_kernel(DecodeK d)
+{
+    const long total = d.nboxes * d.classes;
+    const int size = d.classes + 5;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int j = (int)(idx % d.classes);
+        const long gi = idx / d.classes;
+        const float *x = d.pred + gi * size;
+        float scale = x[4];
+        if (d.classfix == -1 && scale < .5) scale = 0;
+        const float prob = scale * x[5 + j];
+        float v = (prob > d.thresh) ? prob : 0;
+        if (d.only_objectness && j == 0) v = scale;
+        d.probs[idx] = v;
+    }
+}
+
+extern "C" int y2h_region_boxes(const y2h_decode *q, y2h_stream s)
+{
+    if (!q || !q->pred || !q->boxes || !q->probs || !q->anchors) return Y2H_EINVAL;
+    if (q->batch <= 0 || q->w <= 0 || q->h <= 0 || q->num <= 0 || q->classes <= 0) return Y2H_EINVAL;
+    if (q->map && (!q->tree_parent || q->classes < 200)) return Y2H_EINVAL;
+    DecodeK d;
+    d.w = q->w; d.h = q->h; d.num = q->num; d.classes = q->classes; d.img_w = q->img_w; d.img_h = q->img_h;
+    d.thresh = q->thresh; d.only_objectness = q->only_objectness; d.classfix = q->classfix;
+    d.anchors = q->anchors; d.parent = q->tree_parent; d.map = q->map;
+    d.pred = q->pred; d.boxes = q->boxes; d.probs = q->probs;
+    d.nboxes = (long)q->batch * q->w * q->h * q->num;
+    hipLaunchKernelGGL(decode_boxes_kernel, dim3((unsigned)((d.nboxes + 63) / 64)), dim3(64), 0, S(s), d);
+    Y2H_LAUNCH_CHECK();
+    if (!d.parent) {
+        hipLaunchKernelGGL(decode_probs_kernel, dim3(y2h_grid(d.nboxes * d.classes, 256)), dim3(256), 0, S(s), d);
+        Y2H_LAUNCH_CHECK();
+    }
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// box_iou (box.c:67-97): no guard for 0/0, exactly as the reference
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float overlap1(float x1, float w1, float x2, float w2)
+{
+    const float l1 = x1 - w1 / 2, l2 = x2 - w2 / 2;
+    const float left = l1 > l2 ? l1 : l2;
+    const float r1 = x1 + w1 / 2, r2 = x2 + w2 / 2;
+    const float right = r1 < r2 ? r1 : r2;
+    return right - left;
+}
+__device__ __forceinline__ float box_iou_f(float4 a, float4 b)
+{
+    const float w = overlap1(a.x, a.z, b.x, b.z);
+    const float h = overlap1(a.y, a.w, b.y, b.w);
+    const float inter = (w < 0 || h < 0) ? 0 : w * h;
+    const float uni = a.z * a.w + b.z * b.w - inter;
+    return inter / uni;
+}
+
+// ---------------------------------------------------------------------------
+// do_nms_sort (box.c:249-277): per class, sort by score descending, then greedy
+// suppression.  One workgroup per (image, class):
+//   1. gather the non-zero scores of the class into LDS as 64-bit keys
+//      (score bits << 32 | ~box index): descending key order = descending score,
+//      ties by ascending box index (the order a stable sort gives from the
+//      reference's initial ascending array);
+//   2. bitonic sort the keys in LDS;
+//   3. walk the sorted list: a live entry kills every later entry whose IoU with
+//      it exceeds thresh (all lanes test later entries in parallel);
+//   4. zero the killed scores in the probs array.
+// Zero scores never act and zeroing them again is a no-op, so restricting the
+// sort to non-zero scores is exactly the reference's result.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__ boxes, float *__restrict__ probs,
+                                                       int total, int classes, int stride, float thresh, int cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
+    unsigned long long *keys = (unsigned long long *)nms_smem;          // [cap]
+    unsigned char *dead = (unsigned char *)(keys + cap);                // [cap]
+    __shared__ int s_count;
+
+    const int k = blockIdx.x % classes;
+    const int b = blockIdx.x / classes;
+    const float *bx = boxes + (size_t)b * total * 4;
+    float *pr = probs + (size_t)b * total * stride;
+    const int t = threadIdx.x;
+
+    if (t == 0) s_count = 0;
+    __syncthreads();
+    for (int i = t; i < total; i += 256) {
+        const float p = pr[(size_t)i * stride + k];
+        if (p != 0) {
+            const int slot = atomicAdd(&s_count, 1);
+            keys[slot] = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned)(~(unsigned)i);
+        }
+    }
+    __syncthreads();
+    const int n = s_count;
+    if (n < 2) return;                       // nothing can be suppressed
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + t; i < np2; i += 256) keys[i] = 0ull;
+    for (int i = t; i < np2; i += 256) dead[i] = 0;
+    __syncthreads();
+    // bitonic sort, descending
+    for (int kk = 2; kk <= np2; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < np2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], c = keys[ixj];
+                    const bool desc = ((i & kk) == 0);
+                    if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // greedy suppression in sorted order
+    for (int i = 0; i < n - 1; ++i) {
+        if (!dead[i]) {                      // uniform: every lane reads the same LDS byte
+            const unsigned ia = ~(unsigned)(keys[i] & 0xffffffffull);
+            const float4 a = *(const float4 *)(bx + (size_t)ia * 4);
+            for (int j = i + 1 + t; j < n; j += 256) {
+                const unsigned ib = ~(unsigned)(keys[j] & 0xffffffffull);
+                const float4 c = *(const float4 *)(bx + (size_t)ib * 4);
+                if (box_iou_f(a, c) > thresh) dead[j] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = t; j < n; j += 256)
+        if (dead[j]) {
+            const unsigned ib = ~(unsigned)(keys[j] & 0xffffffffull);
+            pr[(size_t)ib * stride + k] = 0;
+        }
+}
+
+extern "C" int y2h_nms_sort(const float *boxes, float *probs, int batch, int total, int classes, int stride,
+                            float thresh, y2h_stream s)
+{
+    if (!boxes || !probs || batch <= 0 || total <= 0 || classes <= 0 || stride < classes) return Y2H_EINVAL;
+    if (total > 16384) return Y2H_EINVAL;            // LDS holds every candidate of one class
+    int cap = 1;
+    while (cap < total) cap <<= 1;
+    const size_t lds = (size_t)cap * 9;
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    Y2H_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        Y2H_CHECK(hipFuncSetAttribute((const void *)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 9));
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)(batch * classes)), dim3(256), lds, S(s),
+                       boxes, probs, total, classes, stride, thresh, cap);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// do_nms (box.c:279-298), the class-agnostic variant demo.c uses.  Sequential
+// in i by construction; one workgroup per image.  For a fixed i the inner j
+// loop is independent per class, so lanes take classes and walk j in order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_plain_kernel(const float *__restrict__ boxes, float *__restrict__ probs,
+                                                        int total, int classes, int stride, float thresh)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ov[];   // [total] overlap flags for the current i
+    __shared__ int s_any;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *bx = boxes + (size_t)b * total * 4;
+    float *pr = probs + (size_t)b * total * stride;
+    for (int i = 0; i < total; ++i) {
+        if (t == 0) s_any = 0;
+        __syncthreads();
+        int any = 0;
+        for (int k = t; k < classes; k += 256) any |= (pr[(size_t)i * stride + k] > 0);
+        if (any) s_any = 1;
+        __syncthreads();
+        if (!s_any) continue;                // uniform
+        const float4 a = *(const float4 *)(bx + (size_t)i * 4);
+        for (int j = i + 1 + t; j < total; j += 256)
+            ov[j] = box_iou_f(a, *(const float4 *)(bx + (size_t)j * 4)) > thresh;
+        __syncthreads();
+        for (int k = t; k < classes; k += 256) {
+            float pi = pr[(size_t)i * stride + k];
+            for (int j = i + 1; j < total; ++j) {
+                if (!ov[j]) continue;
+                float *pj = &pr[(size_t)j * stride + k];
+                if (pi < *pj) pi = 0;
+                else *pj = 0;
+            }
+            pr[(size_t)i * stride + k] = pi;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int y2h_nms(const float *boxes, float *probs, int batch, int total, int classes, int stride,
+                       float thresh, y2h_stream s)
+{
+    if (!boxes || !probs || batch <= 0 || total <= 0 || classes <= 0 || stride < classes) return Y2H_EINVAL;
+    if (total > 65536) return Y2H_EINVAL;
+    hipLaunchKernelGGL(nms_plain_kernel, dim3((unsigned)batch), dim3(256), (size_t)((total + 15) / 16 * 16), S(s),
+                       boxes, probs, total, classes, stride, thresh);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// collect: per image, in ascending box order, keep boxes whose best class
+// (utils.c:533 max_index: first maximum) has prob > thresh
+// (yolo_v2_class.cpp:221-238, image.c:662-672).  Ordered compaction by a
+// workgroup-wide prefix sum so the record order equals the reference's loop order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ boxes, const float *__restrict__ probs,
+                                                      int total, int classes, int stride, float thresh,
+                                                      float *__restrict__ records, int *__restrict__ counts, int max_per)
+{
+    __shared__ int s_scan[256];
+    __shared__ int s_base;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *bx = boxes + (size_t)b * total * 4;
+    const float *pr = probs + (size_t)b * total * stride;
+    float *rec = records + (size_t)b * max_per * 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < total; i0 += 256) {
+        const int i = i0 + t;
+        int cls = 0;
+        float best = 0;
+        int keep = 0;
+        if (i < total) {
+            const float *p = pr + (size_t)i * stride;
+            best = p[0];
+            for (int k = 1; k < classes; ++k) if (p[k] > best) { best = p[k]; cls = k; }
+            keep = best > thresh;
+        }
+        s_scan[t] = keep;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {       // inclusive Hillis-Steele scan
+            const int v = (t >= off) ? s_scan[t - off] : 0;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        const int pos = s_base + s_scan[t] - keep;
+        if (keep && pos < max_per) {
+            float *r = rec + (size_t)pos * 6;
+            r[0] = bx[(size_t)i * 4 + 0]; r[1] = bx[(size_t)i * 4 + 1];
+            r[2] = bx[(size_t)i * 4 + 2]; r[3] = bx[(size_t)i * 4 + 3];
+            r[4] = best; r[5] = (float)cls;
+        }
+        __syncthreads();
+        if (t == 255) s_base += s_scan[255];
+        __syncthreads();
+    }
+    if (t == 0) counts[b] = s_base;
+}
+
+extern "C" int y2h_collect(const float *boxes, const float *probs, int batch, int total, int classes, int stride,
+                           float thresh, float *records, int *counts, int max_per_image, y2h_stream s)
+{
+    if (!boxes || !probs || !records || !counts || batch <= 0 || total <= 0 || classes <= 0 || stride < classes ||
+        max_per_image <= 0) return Y2H_EINVAL;
+    hipLaunchKernelGGL(collect_kernel, dim3((unsigned)batch), dim3(256), 0, S(s),
+                       boxes, probs, total, classes, stride, thresh, records, counts, max_per_image);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// resize_image (image.c:1950-1992): separable align-corners bilinear, two fp32
+// passes (columns first into `tmp` [c][ih][w], then rows), same rounding order
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_cols_kernel(const float *__restrict__ src, float *__restrict__ part,
+                                                          int c, int ih, int iw, int w, float w_scale)
+{
+    const long total = (long)c * ih * w;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int col = (int)(idx % w);
+        const long kr = idx / w;                        // k*ih + r
+        const float *row = src + kr * iw;
+        float val;
+        if (col == w - 1 || iw == 1) val = row[iw - 1];
+        else {
+            const float sx = col * w_scale;
+            const int ix = (int)sx;
+            const float dx = sx - ix;
+            val = (1 - dx) * row[ix] + dx * row[ix + 1];
+        }
+        part[idx] = val;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_rows_kernel(const float *__restrict__ part, float *__restrict__ dst,
+                                                          int c, int ih, int w, int h, float h_scale)
+{
+    const long total = (long)c * h * w;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int col = (int)(idx % w);
+        const int r = (int)((idx / w) % h);
+        const int k = (int)(idx / ((long)w * h));
+        const float sy = r * h_scale;
+        const int iy = (int)sy;
+        const float dy = sy - iy;
+        const float *p = part + ((long)k * ih + iy) * w + col;
+        float val = (1 - dy) * p[0];
+        if (!(r == h - 1 || ih == 1)) val = val + dy * p[w];
+        dst[idx] = val;
+    }
+}
+
+extern "C" int y2h_resize_chw(const float *src, int c, int ih, int iw, float *tmp, float *dst, int h, int w, y2h_stream s)
+{
+    if (!src || !tmp || !dst || c <= 0 || ih <= 0 || iw <= 0 || h <= 0 || w <= 0) return Y2H_EINVAL;
+    const float w_scale = (float)(iw - 1) / (w - 1);
+    const float h_scale = (float)(ih - 1) / (h - 1);
+    hipLaunchKernelGGL(resize_cols_kernel, dim3(y2h_grid((long)c * ih * w, 256)), dim3(256), 0, S(s), src, tmp, c, ih, iw, w, w_scale);
+    Y2H_LAUNCH_CHECK();
+    hipLaunchKernelGGL(resize_rows_kernel, dim3(y2h_grid((long)c * h * w, 256)), dim3(256), 0, S(s), tmp, dst, c, ih, w, h, h_scale);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

@@ -1,0 +1,256 @@
+// Non-convolution layers of the forward path, NHWC fp32 (include/y2_hip.h).
+// All of these are HBM-bound copies/reductions; the arithmetic follows the
+// reference CPU order exactly so results are bit-identical to it.
+// Compiled with -ffp-contract=off.
+#include "y2_common.hpp"
+#include <float.h>
+
+// ---------------------------------------------------------------------------
+// maxpool  (src_yolo2/maxpool_layer.c:79-114; CUDA twin maxpool_layer_kernels.cu:10)
+// window origin = -pad + o*stride, out-of-image taps read as -FLT_MAX, strict '>'
+// ---------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy,
+                                                      int h, int w, int c, int size, int stride, int pad,
+                                                      int out_h, int out_w, long total)
+{
+    const int cv = c / V;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % cv);
+        const long op = idx / cv;
+        const int ox = (int)(op % out_w);
+        const int oy = (int)((op / out_w) % out_h);
+        const long n = op / ((long)out_w * out_h);
+        float m[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) m[v] = -FLT_MAX;
+        for (int kh = 0; kh < size; ++kh) {
+            const int iy = -pad + oy * stride + kh;
+            for (int kw = 0; kw < size; ++kw) {
+                const int ix = -pad + ox * stride + kw;
+                if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+                    const float *src = x + ((n * h + iy) * (long)w + ix) * ldx + cg * V;
+                    if (V == 4) {
+                        const float4 q = *(const float4 *)src;
+                        m[0] = (q.x > m[0]) ? q.x : m[0];
+                        m[1 % V] = (q.y > m[1 % V]) ? q.y : m[1 % V];
+                        m[2 % V] = (q.z > m[2 % V]) ? q.z : m[2 % V];
+                        m[3 % V] = (q.w > m[3 % V]) ? q.w : m[3 % V];
+                    } else {
+                        const float q = *src;
+                        m[0] = (q > m[0]) ? q : m[0];
+                    }
+                }
+            }
+        }
+        float *dst = y + op * ldy + cg * V;
+        if (V == 4) *(float4 *)dst = make_float4(m[0], m[1 % V], m[2 % V], m[3 % V]);
+        else *dst = m[0];
+    }
+}
+
+extern "C" int y2h_maxpool(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c,
+                           int size, int stride, int pad, int out_h, int out_w, y2h_stream s)
+{
+    if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || size <= 0 || stride <= 0 || ldx < c || ldy < c) return Y2H_EINVAL;
+    if (out_h != (h + 2 * pad) / stride || out_w != (w + 2 * pad) / stride) return Y2H_EINVAL;
+    const bool v4 = (c % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    const long npix = (long)batch * out_h * out_w;
+    if (v4) {
+        const long total = npix * (c / 4);
+        hipLaunchKernelGGL(maxpool_kernel<4>, dim3(y2h_grid(total, 256, 256 * 32)), dim3(256), 0, S(s),
+                           x, ldx, y, ldy, h, w, c, size, stride, pad, out_h, out_w, total);
+    } else {
+        const long total = npix * c;
+        hipLaunchKernelGGL(maxpool_kernel<1>, dim3(y2h_grid(total, 256, 256 * 32)), dim3(256), 0, S(s),
+                           x, ldx, y, ldy, h, w, c, size, stride, pad, out_h, out_w, total);
+    }
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// reorg  (src_yolo2/blas.c:8-29 reorg_cpu as called by reorg_layer.c:78-85)
+//
+// The reference works on flat NCHW indices.  For the ordinary (non-reverse)
+// layer it calls reorg_cpu(x, w,h,c, batch, stride, forward=0, out): for every
+// flat index f of the input-shaped iteration space (k,j,i) it gathers
+//   out[f] = x[ w2 + w*s*(h2 + h*s*c2) ],  c2 = k % (c/s^2), off = k / (c/s^2),
+//   w2 = i*s + off % s, h2 = j*s + off / s
+// and the result is then *labelled* [c*s*s][h/s][w/s].  This kernel computes
+// the same gather with both tensors in NHWC: flat output index f is decoded
+// in the output's label geometry to find where it lives in NHWC, and the flat
+// source index is decoded in the input's [c][h][w] geometry.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reorg_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy,
+                                                    int h, int w, int c, int s, int reverse, long total)
+{
+    const int oc_small = c / (s * s);
+    // label geometry of the output
+    const int lo_c = reverse ? oc_small : c * s * s;
+    const int lo_h = reverse ? h * s : h / s;
+    const int lo_w = reverse ? w * s : w / s;
+    const long per = (long)c * h * w;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        // idx enumerates NHWC output elements: (b, yo, xo, co), co fastest
+        const int co = (int)(idx % lo_c);
+        const long opix = idx / lo_c;
+        const int xo = (int)(opix % lo_w);
+        const int yo = (int)((opix / lo_w) % lo_h);
+        const long b = opix / ((long)lo_w * lo_h);
+        const long f = ((long)co * lo_h + yo) * lo_w + xo;     // flat NCHW index of this output element
+        long q;                                                // flat NCHW index of the source element
+        if (!reverse) {
+            const int i = (int)(f % w);
+            const int j = (int)((f / w) % h);
+            const int k = (int)(f / ((long)w * h));
+            const int c2 = k % oc_small, off = k / oc_small;
+            const int w2 = i * s + off % s, h2 = j * s + off / s;
+            q = w2 + (long)w * s * (h2 + (long)h * s * c2);
+        } else {
+            // forward=1: out[out_index] = x[in_index]; invert out_index = w2 + w*s*(h2 + h*s*c2)
+            const int w2 = (int)(f % ((long)w * s));
+            const int h2 = (int)((f / ((long)w * s)) % ((long)h * s));
+            const int c2 = (int)(f / ((long)w * s * h * s));
+            const int i = w2 / s, j = h2 / s;
+            const int off = (h2 % s) * s + (w2 % s);
+            const int k = off * oc_small + c2;
+            q = i + (long)w * (j + (long)h * k);
+        }
+        const int xi = (int)(q % w);
+        const int yi = (int)((q / w) % h);
+        const int ci = (int)(q / ((long)w * h));
+        (void)per;
+        y[opix * ldy + co] = x[((b * h + yi) * (long)w + xi) * ldx + ci];
+    }
+}
+
+extern "C" int y2h_reorg(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c,
+                         int stride, int reverse, y2h_stream s)
+{
+    if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || stride <= 0 || ldx < c) return Y2H_EINVAL;
+    if (c % (stride * stride) != 0) return Y2H_EINVAL;
+    if (!reverse && (h % stride != 0 || w % stride != 0)) return Y2H_EINVAL;
+    const int oc = reverse ? c / (stride * stride) : c * stride * stride;
+    if (ldy < oc) return Y2H_EINVAL;
+    const long total = (long)batch * h * w * c;
+    hipLaunchKernelGGL(reorg_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), x, ldx, y, ldy, h, w, c, stride,
+                       reverse ? 1 : 0, total);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// global average pool (src_yolo2/avgpool_layer.c:40-54): sequential fp32 sum, one divide
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
+                                                      int hw, int c, long total)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % c);
+        const long b = idx / c;
+        const float *src = x + b * hw * (long)ldx + k;
+        float sum = 0.f;
+        for (int i = 0; i < hw; ++i) sum += src[(long)i * ldx];
+        y[idx] = sum / hw;
+    }
+}
+
+extern "C" int y2h_avgpool(const float *x, int ldx, float *y, int batch, int h, int w, int c, y2h_stream s)
+{
+    if (batch <= 0 || h <= 0 || w <= 0 || c <= 0 || ldx < c) return Y2H_EINVAL;
+    const long total = (long)batch * c;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), x, ldx, y, h * w, c, total);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// softmax (src_yolo2/blas.c:205-221): max-subtract, exp in double, fp32 running
+// sum in index order, divide.  One thread walks one row (or one tree group) so
+// the summation order is the reference's.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void softmax_seq(const float *in, int n, float temp, float *out)
+{
+    float sum = 0.f, largest = -FLT_MAX;
+    for (int i = 0; i < n; ++i) if (in[i] > largest) largest = in[i];
+    for (int i = 0; i < n; ++i) {
+        const float e = (float)exp((double)(in[i] / temp - largest / temp));
+        sum += e;
+        out[i] = e;
+    }
+    for (int i = 0; i < n; ++i) out[i] /= sum;
+}
+
+__global__ __launch_bounds__(64) void softmax_rows_kernel(const float *x, float *y, long rows, int n, float temp)
+{
+    const long r = (long)blockIdx.x * 64 + threadIdx.x;
+    if (r < rows) softmax_seq(x + r * n, n, temp, y + r * n);
+}
+
+extern "C" int y2h_softmax_rows(const float *x, float *y, long rows, int n, float temp, y2h_stream s)
+{
+    if (rows <= 0 || n <= 0) return Y2H_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, S(s), x, y, rows, n, temp);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// region head (src_yolo2/region_layer.c:144-177, CPU build): the conv output in
+// NHWC *is* the reference's flattened layout [cell][anchor][tx,ty,tw,th,obj,cls..]
+// (blas.c:31 flatten), so this is a copy with logistic on objectness
+// (activations.h:35, double) and softmax / tree softmax on the class scores.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void region_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
+                                                    long boxes, int hw, int num, int classes, int coords, int softmax)
+{
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;   // box index over batch*hw*num
+    if (i >= boxes) return;
+    const int size = coords + 1 + classes;
+    const int a = (int)(i % num);
+    const long cell = i / num;                             // b*hw + cell
+    const float *src = x + cell * ldx + (long)a * size;
+    float *dst = y + i * size;
+    for (int k = 0; k < coords; ++k) dst[k] = src[k];
+    dst[coords] = (float)(1. / (1. + exp(-(double)src[coords])));
+    if (softmax == 1) softmax_seq(src + coords + 1, classes, 1.f, dst + coords + 1);
+    else if (softmax == 0) for (int k = 0; k < classes; ++k) dst[coords + 1 + k] = src[coords + 1 + k];
+    // softmax == 2: tree; class scores are produced by region_tree_kernel
+}
+
+__global__ __launch_bounds__(256) void region_tree_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
+                                                          long boxes, int num, int classes, int coords, int groups,
+                                                          const int *__restrict__ gsize, const int *__restrict__ goff)
+{
+    const long total = boxes * groups;
+    const int size = coords + 1 + classes;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int g = (int)(idx % groups);
+        const long i = idx / groups;
+        const int a = (int)(i % num);
+        const long cell = i / num;
+        const float *src = x + cell * ldx + (long)a * size + coords + 1 + goff[g];
+        float *dst = y + i * size + coords + 1 + goff[g];
+        softmax_seq(src, gsize[g], 1.f, dst);
+    }
+}
+
+extern "C" int y2h_region_forward(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
+                                  int softmax, int groups, const int *group_size, const int *group_offset, y2h_stream s)
+{
+    if (batch <= 0 || hw <= 0 || num <= 0 || classes <= 0 || coords != 4) return Y2H_EINVAL;
+    if (ldx < num * (coords + 1 + classes)) return Y2H_EINVAL;
+    const long boxes = (long)batch * hw * num;
+    const int mode = groups > 0 ? 2 : (softmax ? 1 : 0);
+    hipLaunchKernelGGL(region_kernel, dim3((unsigned)((boxes + 63) / 64)), dim3(64), 0, S(s),
+                       x, ldx, y, boxes, hw, num, classes, coords, mode);
+    Y2H_LAUNCH_CHECK();
+    if (groups > 0) {
+        if (!group_size || !group_offset) return Y2H_EINVAL;
+        hipLaunchKernelGGL(region_tree_kernel, dim3(y2h_grid(boxes * groups, 256, 256 * 64)), dim3(256), 0, S(s),
+                           x, ldx, y, boxes, num, classes, coords, groups, group_size, group_offset);
+        Y2H_LAUNCH_CHECK();
+    }
+    return Y2H_OK;
+}

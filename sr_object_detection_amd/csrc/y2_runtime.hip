@@ -1,0 +1,200 @@
+// Device, memory, stream and layout entry points of the C-ABI HIP layer
+// (include/y2_hip.h).  Replaces the reference's cuda.c wrapper
+// (src_yolo2/cuda.c:12-160); unlike it, nothing here aborts -- errors come
+// back as codes and the text is kept for y2h_last_error().
+#include "y2_common.hpp"
+
+static thread_local char g_err[512] = "";
+static char g_name[256] = "";
+
+extern "C" void y2h_set_error_(const char *what, const char *detail)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, detail ? detail : "");
+}
+
+extern "C" const char *y2h_last_error(void) { return g_err; }
+
+extern "C" int y2h_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int y2h_set_device(int dev) { Y2H_CHECK(hipSetDevice(dev)); return Y2H_OK; }
+extern "C" int y2h_get_device(int *dev) { Y2H_CHECK(hipGetDevice(dev)); return Y2H_OK; }
+
+extern "C" const char *y2h_device_name(void)
+{
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return "";
+    snprintf(g_name, sizeof g_name, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return g_name;
+}
+
+extern "C" int y2h_malloc(void **ptr, size_t bytes) { Y2H_CHECK(hipMalloc(ptr, bytes ? bytes : 16)); return Y2H_OK; }
+extern "C" int y2h_free(void *ptr) { if (ptr) Y2H_CHECK(hipFree(ptr)); return Y2H_OK; }
+extern "C" int y2h_host_alloc(void **ptr, size_t bytes) { Y2H_CHECK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault)); return Y2H_OK; }
+extern "C" int y2h_host_free(void *ptr) { if (ptr) Y2H_CHECK(hipHostFree(ptr)); return Y2H_OK; }
+
+extern "C" int y2h_memcpy_h2d(void *dst, const void *src, size_t bytes, y2h_stream s)
+{
+    if (bytes) Y2H_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(s)));
+    return Y2H_OK;
+}
+extern "C" int y2h_memcpy_d2h(void *dst, const void *src, size_t bytes, y2h_stream s)
+{
+    if (bytes) Y2H_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(s)));
+    return Y2H_OK;
+}
+extern "C" int y2h_memcpy_d2d(void *dst, const void *src, size_t bytes, y2h_stream s)
+{
+    if (bytes) Y2H_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)));
+    return Y2H_OK;
+}
+extern "C" int y2h_memset(void *dst, int value, size_t bytes, y2h_stream s)
+{
+    if (bytes) Y2H_CHECK(hipMemsetAsync(dst, value, bytes, S(s)));
+    return Y2H_OK;
+}
+
+extern "C" int y2h_stream_create(y2h_stream *s)
+{
+    hipStream_t st;
+    Y2H_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *s = (y2h_stream)st;
+    return Y2H_OK;
+}
+extern "C" int y2h_stream_destroy(y2h_stream s) { if (s) Y2H_CHECK(hipStreamDestroy(S(s))); return Y2H_OK; }
+extern "C" int y2h_stream_sync(y2h_stream s) { Y2H_CHECK(hipStreamSynchronize(S(s))); return Y2H_OK; }
+extern "C" int y2h_device_sync(void) { Y2H_CHECK(hipDeviceSynchronize()); return Y2H_OK; }
+
+extern "C" int y2h_event_create(y2h_event *e)
+{
+    hipEvent_t ev;
+    Y2H_CHECK(hipEventCreate(&ev));
+    *e = (y2h_event)ev;
+    return Y2H_OK;
+}
+extern "C" int y2h_event_destroy(y2h_event e) { if (e) Y2H_CHECK(hipEventDestroy((hipEvent_t)e)); return Y2H_OK; }
+extern "C" int y2h_event_record(y2h_event e, y2h_stream s) { Y2H_CHECK(hipEventRecord((hipEvent_t)e, S(s))); return Y2H_OK; }
+extern "C" int y2h_event_elapsed_ms(y2h_event start, y2h_event stop, float *ms)
+{
+    Y2H_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    Y2H_CHECK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// layout kernels
+// ---------------------------------------------------------------------------
+
+// NCHW -> NHWC through an LDS tile so both sides stay coalesced:
+// a block moves 64 pixels x 32 channels.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int c, long hw, int ld)
+{
+    __shared__ float tile[32][65];
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int n = blockIdx.z;
+    const float *s = src + (long)n * c * hw;
+    float *d = dst + (long)n * hw * ld;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    for (int cc = ty; cc < 32; cc += 4) {
+        const int ch = c0 + cc;
+        const long p = p0 + tx;
+        tile[cc][tx] = (ch < c && p < hw) ? s[(long)ch * hw + p] : 0.f;
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;   // 32 x 8
+    for (int pp = py; pp < 64; pp += 8) {
+        const long p = p0 + pp;
+        const int ch = c0 + cx;
+        if (ch < c && p < hw) d[p * ld + ch] = tile[cx][pp];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ src, int ld, float *__restrict__ dst,
+                                                           int c, long hw)
+{
+    __shared__ float tile[32][65];
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32;
+    const int n = blockIdx.z;
+    const float *s = src + (long)n * hw * ld;
+    float *d = dst + (long)n * c * hw;
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    for (int pp = py; pp < 64; pp += 8) {
+        const long p = p0 + pp;
+        const int ch = c0 + cx;
+        tile[cx][pp] = (ch < c && p < hw) ? s[p * ld + ch] : 0.f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int cc = ty; cc < 32; cc += 4) {
+        const int ch = c0 + cc;
+        const long p = p0 + tx;
+        if (ch < c && p < hw) d[(long)ch * hw + p] = tile[cc][tx];
+    }
+}
+
+extern "C" int y2h_nchw_to_nhwc(const float *src, float *dst, int n, int c, int h, int w, int ld, y2h_stream s)
+{
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || ld < c) return Y2H_EINVAL;
+    const long hw = (long)h * w;
+    dim3 grid((unsigned)((hw + 63) / 64), (unsigned)((c + 31) / 32), (unsigned)n);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, S(s), src, dst, c, hw, ld);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+extern "C" int y2h_nhwc_to_nchw(const float *src, int ld, float *dst, int n, int c, int h, int w, y2h_stream s)
+{
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || ld < c) return Y2H_EINVAL;
+    const long hw = (long)h * w;
+    dim3 grid((unsigned)((hw + 63) / 64), (unsigned)((c + 31) / 32), (unsigned)n);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, S(s), src, ld, dst, c, hw);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float *__restrict__ src, int ld_src,
+                                                            float *__restrict__ dst, int ld_dst, int c, long total)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / c;
+        const int ch = (int)(i - p * c);
+        dst[p * ld_dst + ch] = src[p * ld_src + ch];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_channels4_kernel(const float4 *__restrict__ src, int ld_src4,
+                                                             float4 *__restrict__ dst, int ld_dst4, int c4, long total)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long p = i / c4;
+        const int ch = (int)(i - p * c4);
+        dst[p * ld_dst4 + ch] = src[p * ld_src4 + ch];
+    }
+}
+
+extern "C" int y2h_copy_channels(const float *src, int ld_src, float *dst, int ld_dst, int c, long npix, y2h_stream s)
+{
+    if (c <= 0 || npix <= 0) return Y2H_OK;
+    if (ld_src < c || ld_dst < c) return Y2H_EINVAL;
+    const bool v4 = (c % 4 == 0) && (ld_src % 4 == 0) && (ld_dst % 4 == 0) &&
+                    (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    if (v4) {
+        const long total = npix * (c / 4);
+        hipLaunchKernelGGL(copy_channels4_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s),
+                           (const float4 *)src, ld_src / 4, (float4 *)dst, ld_dst / 4, c / 4, total);
+    } else {
+        const long total = npix * c;
+        hipLaunchKernelGGL(copy_channels_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s),
+                           src, ld_src, dst, ld_dst, c, total);
+    }
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

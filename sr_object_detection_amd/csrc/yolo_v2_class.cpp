@@ -1,0 +1,226 @@
+// Detector: the C++ face of the engine (reference: src_yolo2/yolo_v2_class.cpp).
+//
+//  ctor     cpp:37-81    parse_network_cfg + load_weights + set_batch_network(1)
+//  detect   cpp:173-249  (resize) -> predict -> get_region_boxes(1,1,thresh) ->
+//                        do_nms_sort(nms) -> bbox_t conversion with unsigned truncation
+//  tracking cpp:251-303  nearest-centre (< 100 px) track-id hand-over across frames
+//
+// Without use_mean the whole chain runs as the fused HBM-resident y2_detect();
+// with use_mean the 3-frame average of the raw predictions (cpp:208-213) is
+// formed first and decoded through get_region_boxes / do_nms_sort.
+#include "yolo_v2_class.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+#include "sr_yolo2.h"
+
+extern "C" void y2_set_error_mode(int mode);
+
+namespace {
+
+const int kFrames = 3;
+
+struct DetectorState {
+    network net;
+    std::vector<float> avg;
+    std::vector<float> predictions[kFrames];
+    int demo_index = 0;
+    std::vector<unsigned int> next_track_id;     // per class
+    std::vector<y2_det> dets;
+    std::vector<box> boxes;
+    std::vector<float> probs_flat;
+    std::vector<float *> probs;
+};
+
+DetectorState &state_of(const std::shared_ptr<void> &p) { return *static_cast<DetectorState *>(p.get()); }
+
+bbox_t to_bbox(float bx, float by, float bw, float bh, float prob, int cls, int im_w, int im_h)
+{
+    // cpp:229-235: doubles, clamped at 0, then truncated to unsigned
+    bbox_t r;
+    r.x = (unsigned int)std::max((double)0, (bx - bw / 2.) * im_w);
+    r.y = (unsigned int)std::max((double)0, (by - bh / 2.) * im_h);
+    r.w = (unsigned int)(bw * im_w);
+    r.h = (unsigned int)(bh * im_h);
+    r.prob = prob;
+    r.obj_id = (unsigned int)cls;
+    r.track_id = 0;
+    return r;
+}
+
+}  // namespace
+
+Detector::Detector(std::string cfg_filename, std::string weight_filename, int gpu_id)
+{
+    auto *st = new DetectorState();
+    detector_gpu_ptr = std::shared_ptr<void>(st, [](void *p) { delete static_cast<DetectorState *>(p); });
+    const int saved = gpu_index;
+    gpu_index = gpu_id;
+    st->net = parse_network_cfg(const_cast<char *>(cfg_filename.c_str()));
+    gpu_index = saved;
+    if (!st->net.layers) throw std::runtime_error(std::string("cannot build network: ") + y2_last_error());
+    st->net.gpu_index = gpu_id;
+    if (!weight_filename.empty()) load_weights(&st->net, const_cast<char *>(weight_filename.c_str()));
+    set_batch_network(&st->net, 1);
+    const layer &l = st->net.layers[st->net.n - 1];
+    st->avg.assign(l.outputs, 0.f);
+    for (auto &p : st->predictions) p.assign(l.outputs, 0.f);
+    st->next_track_id.assign(std::max(l.classes, 1), 1u);
+    const int total = l.w * l.h * l.n;
+    st->dets.resize(std::max(total, 1));
+    st->boxes.resize(std::max(total, 1));
+    st->probs_flat.assign((size_t)std::max(total, 1) * std::max(l.classes, 1), 0.f);
+    st->probs.resize(std::max(total, 1));
+    for (int i = 0; i < total; ++i) st->probs[i] = st->probs_flat.data() + (size_t)i * l.classes;
+}
+
+Detector::~Detector()
+{
+    if (detector_gpu_ptr) free_network(state_of(detector_gpu_ptr).net);
+}
+
+int Detector::get_net_width() const { return state_of(detector_gpu_ptr).net.w; }
+int Detector::get_net_height() const { return state_of(detector_gpu_ptr).net.h; }
+
+// Binary PPM (P6, maxval 255) reader.  The reference decodes JPEG/PNG through the vendored
+// stb_image (cpp:127-149); file decoding is outside the engine, so only the dependency-free
+// format is read here -- callers with other formats fill image_t themselves (or use OpenCV).
+image_t Detector::load_image(std::string image_filename)
+{
+    FILE *f = std::fopen(image_filename.c_str(), "rb");
+    if (!f) throw std::runtime_error("file not found");
+    int w = 0, h = 0, maxv = 0;
+    char magic[3] = {0, 0, 0};
+    if (std::fscanf(f, "%2s", magic) != 1 || std::strcmp(magic, "P6") != 0) { std::fclose(f); throw std::runtime_error("load_image: only binary PPM (P6) is supported"); }
+    int got = 0, vals[3];
+    while (got < 3) {
+        int ch = std::fgetc(f);
+        if (ch == '#') { while (ch != '\n' && ch != EOF) ch = std::fgetc(f); continue; }
+        if (ch == EOF) break;
+        if (std::isspace(ch)) continue;
+        std::ungetc(ch, f);
+        if (std::fscanf(f, "%d", &vals[got]) != 1) break;
+        ++got;
+    }
+    if (got != 3) { std::fclose(f); throw std::runtime_error("load_image: bad PPM header"); }
+    w = vals[0]; h = vals[1]; maxv = vals[2];
+    std::fgetc(f);
+    if (w <= 0 || h <= 0 || maxv != 255) { std::fclose(f); throw std::runtime_error("load_image: unsupported PPM"); }
+    std::vector<unsigned char> raw((size_t)w * h * 3);
+    if (std::fread(raw.data(), 1, raw.size(), f) != raw.size()) { std::fclose(f); throw std::runtime_error("load_image: short PPM"); }
+    std::fclose(f);
+    image_t im;
+    im.w = w; im.h = h; im.c = 3;
+    im.data = (float *)std::calloc((size_t)w * h * 3, sizeof(float));
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < h; ++j)
+            for (int i = 0; i < w; ++i)
+                im.data[i + (size_t)w * j + (size_t)w * h * k] = (float)raw[k + 3 * i + 3 * (size_t)w * j] / 255.;
+    return im;
+}
+
+void Detector::free_image(image_t m) { if (m.data) std::free(m.data); }
+
+std::vector<bbox_t> Detector::detect(std::string image_filename, float thresh, bool use_mean)
+{
+    image_t im = load_image(image_filename);
+    std::vector<bbox_t> r;
+    try { r = detect(im, thresh, use_mean); } catch (...) { free_image(im); throw; }
+    free_image(im);
+    return r;
+}
+
+std::vector<bbox_t> Detector::detect(image_t img, float thresh, bool use_mean)
+{
+    DetectorState &st = state_of(detector_gpu_ptr);
+    network &net = st.net;
+    if (!img.data) throw std::runtime_error("Image is empty");
+    image im; im.w = img.w; im.h = img.h; im.c = img.c; im.data = img.data;
+    image sized = im;
+    bool own = false;
+    if (net.w != im.w || net.h != im.h) { sized = resize_image(im, net.w, net.h); own = true; }
+    const layer &last = net.layers[net.n - 1];
+    const int total = last.w * last.h * last.n;
+    std::vector<bbox_t> out;
+    if (!use_mean) {
+        int count = 0;
+        const int rc = y2_detect(net, sized.data, thresh, nms, 1, 1, st.dets.data(), &count, total);
+        if (own) ::free_image(sized);
+        if (rc != 0) throw std::runtime_error(y2_last_error());
+        for (int i = 0; i < std::min(count, total); ++i) {
+            const y2_det &d = st.dets[i];
+            out.push_back(to_bbox(d.x, d.y, d.w, d.h, d.prob, d.obj_id, im.w, im.h));
+        }
+        return out;
+    }
+    float *prediction = network_predict(net, sized.data);
+    if (own) ::free_image(sized);
+    if (!prediction) throw std::runtime_error(y2_last_error());
+    layer l = last;
+    std::memcpy(st.predictions[st.demo_index].data(), prediction, (size_t)l.outputs * sizeof(float));
+    float *rows[kFrames];
+    for (int j = 0; j < kFrames; ++j) rows[j] = st.predictions[j].data();
+    mean_arrays(rows, kFrames, l.outputs, st.avg.data());
+    l.output = st.avg.data();
+    st.demo_index = (st.demo_index + 1) % kFrames;
+    get_region_boxes(l, 1, 1, thresh, st.probs.data(), st.boxes.data(), 0, 0);
+    if (nms) do_nms_sort(st.boxes.data(), st.probs.data(), total, l.classes, nms);
+    for (int i = 0; i < total; ++i) {
+        const int id = max_index(st.probs[i], l.classes);
+        const float prob = st.probs[i][id];
+        if (prob > thresh) {
+            const box &b = st.boxes[i];
+            out.push_back(to_bbox(b.x, b.y, b.w, b.h, prob, id, im.w, im.h));
+        }
+    }
+    return out;
+}
+
+std::vector<bbox_t> Detector::tracking(std::vector<bbox_t> cur, int const frames_story)
+{
+    DetectorState &st = state_of(detector_gpu_ptr);
+    auto remember = [&]() {
+        prev_bbox_vec_deque.push_front(cur);
+        if ((int)prev_bbox_vec_deque.size() > frames_story) prev_bbox_vec_deque.pop_back();
+    };
+    auto fresh_id = [&](bbox_t &b) {
+        if (b.obj_id >= st.next_track_id.size()) st.next_track_id.resize(b.obj_id + 1, 1u);
+        b.track_id = st.next_track_id[b.obj_id]++;
+    };
+    bool history = false;
+    for (auto &v : prev_bbox_vec_deque) if (!v.empty()) history = true;
+    if (!history) {
+        for (auto &b : cur) fresh_id(b);
+        remember();
+        return cur;
+    }
+    std::vector<unsigned int> best(cur.size(), std::numeric_limits<unsigned int>::max());
+    for (auto &frame : prev_bbox_vec_deque) {
+        for (auto &old : frame) {
+            int pick = -1;
+            for (size_t m = 0; m < cur.size(); ++m) {
+                const bbox_t &k = cur[m];
+                if (old.obj_id != k.obj_id) continue;
+                const float dx = (float)(old.x + old.w / 2) - (float)(k.x + k.w / 2);
+                const float dy = (float)(old.y + old.h / 2) - (float)(k.y + k.h / 2);
+                const unsigned int dist = (unsigned int)std::sqrt(dx * dx + dy * dy);
+                if (dist < 100 && (k.track_id == 0 || best[m] > dist)) { best[m] = dist; pick = (int)m; }
+            }
+            const bool taken = std::any_of(cur.begin(), cur.end(), [&](const bbox_t &b) {
+                return b.track_id == old.track_id && b.obj_id == old.obj_id; });
+            if (pick >= 0 && !taken) {
+                cur[pick].track_id = old.track_id;
+                cur[pick].w = (cur[pick].w + old.w) / 2;
+                cur[pick].h = (cur[pick].h + old.h) / 2;
+            }
+        }
+    }
+    for (auto &b : cur) if (b.track_id == 0) fresh_id(b);
+    remember();
+    return cur;
+}

@@ -1,0 +1,441 @@
+"""Python mirror of the reference's C interface for the forward path, bound with
+ctypes to libsr_yolo2.so (the C-ABI library built from csrc/).
+
+The method names, argument meaning and results follow the reference functions
+(src_yolo2/parser.h:5-11, network.h:83-127, region_layer.h:12, box.h:13-17,
+test_detector.h:2) so that the parity tests read like calls into Darknet:
+
+    net = Network.parse_network_cfg("yolo.cfg")
+    net.load_weights("yolo.weights")
+    net.set_batch_network(1)
+    out = net.network_predict(x)                      # float32 [batch*outputs]
+    boxes, probs = net.get_region_boxes(1, 1, thresh)
+    probs = do_nms_sort(boxes, probs, nms)
+
+There is no fallback: if the shared library is missing or no GPU is visible the
+calls raise (the library itself has no CPU compute path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsr_yolo2.so")
+
+
+class Y2Error(RuntimeError):
+    pass
+
+
+class Tree(C.Structure):
+    _fields_ = [("leaf", C.POINTER(C.c_int)), ("n", C.c_int), ("parent", C.POINTER(C.c_int)),
+                ("group", C.POINTER(C.c_int)), ("name", C.POINTER(C.c_char_p)), ("groups", C.c_int),
+                ("group_size", C.POINTER(C.c_int)), ("group_offset", C.POINTER(C.c_int))]
+
+
+class Box(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float)]
+
+
+class Image(C.Structure):
+    _fields_ = [("h", C.c_int), ("w", C.c_int), ("c", C.c_int), ("data", C.POINTER(C.c_float))]
+
+
+class Object(C.Structure):   # utils.h:14-28
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float), ("name", C.c_char * 20),
+                ("prob", C.c_float), ("objClass", C.c_int), ("CameraX", C.c_float), ("CameraY", C.c_float),
+                ("CameraZ", C.c_float), ("CameraWidth", C.c_float), ("CameraHeight", C.c_float),
+                ("flagBelong2Person", C.c_ubyte), ("boxRGB", C.c_float * 3), ("bodyId", C.c_int)]
+
+
+class Layer(C.Structure):    # include/sr_yolo2.h struct layer
+    _fields_ = [
+        ("type", C.c_int), ("activation", C.c_int), ("cost_type", C.c_int),
+        ("batch_normalize", C.c_int), ("batch", C.c_int), ("flipped", C.c_int),
+        ("inputs", C.c_int), ("outputs", C.c_int),
+        ("h", C.c_int), ("w", C.c_int), ("c", C.c_int),
+        ("out_h", C.c_int), ("out_w", C.c_int), ("out_c", C.c_int),
+        ("n", C.c_int), ("groups", C.c_int),
+        ("size", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("reverse", C.c_int), ("index", C.c_int), ("binary", C.c_int), ("xnor", C.c_int),
+        ("softmax", C.c_int), ("classes", C.c_int), ("coords", C.c_int), ("classfix", C.c_int), ("log", C.c_int),
+        ("sqrt", C.c_int), ("max_boxes", C.c_int), ("rescore", C.c_int), ("bias_match", C.c_int), ("random", C.c_int),
+        ("absolute", C.c_int), ("truths", C.c_int),
+        ("jitter", C.c_float), ("thresh", C.c_float), ("coord_scale", C.c_float), ("object_scale", C.c_float),
+        ("noobject_scale", C.c_float), ("class_scale", C.c_float),
+        ("temperature", C.c_float), ("scale", C.c_float),
+        ("dontload", C.c_int), ("dontloadscales", C.c_int),
+        ("softmax_tree", C.POINTER(Tree)), ("map", C.POINTER(C.c_int)),
+        ("input_layers", C.POINTER(C.c_int)), ("input_sizes", C.POINTER(C.c_int)),
+        ("biases", C.POINTER(C.c_float)), ("scales", C.POINTER(C.c_float)), ("weights", C.POINTER(C.c_float)),
+        ("rolling_mean", C.POINTER(C.c_float)), ("rolling_variance", C.POINTER(C.c_float)),
+        ("output", C.POINTER(C.c_float)), ("delta", C.POINTER(C.c_float)), ("cost", C.POINTER(C.c_float)),
+        ("workspace_size", C.c_size_t), ("dev", C.c_void_p),
+    ]
+
+
+class CNetwork(C.Structure):  # include/sr_yolo2.h struct network
+    _fields_ = [
+        ("workspace", C.POINTER(C.c_float)), ("n", C.c_int), ("batch", C.c_int), ("seen", C.POINTER(C.c_int)),
+        ("subdivisions", C.c_int), ("learning_rate", C.c_float), ("momentum", C.c_float), ("decay", C.c_float),
+        ("max_batches", C.c_int), ("time_steps", C.c_int), ("layers", C.POINTER(Layer)), ("outputs", C.c_int),
+        ("output", C.POINTER(C.c_float)), ("inputs", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int),
+        ("gpu_index", C.c_int), ("hierarchy", C.POINTER(Tree)), ("engine", C.c_void_p),
+    ]
+
+
+class Det(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float), ("prob", C.c_float),
+                ("obj_id", C.c_int)]
+
+
+DET_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("w", "<f4"), ("h", "<f4"), ("prob", "<f4"), ("obj_id", "<i4")])
+
+LAYER_TYPES = ["CONVOLUTIONAL", "DECONVOLUTIONAL", "CONNECTED", "MAXPOOL", "SOFTMAX", "DETECTION", "DROPOUT", "CROP",
+               "ROUTE", "COST", "NORMALIZATION", "AVGPOOL", "LOCAL", "SHORTCUT", "ACTIVE", "RNN", "GRU", "CRNN",
+               "BATCHNORM", "NETWORK", "XNOR", "REGION", "REORG", "BLANK"]
+
+_lib = None
+
+
+def lib():
+    """Load libsr_yolo2.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Y2Error("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(make -C sr_object_detection_amd/csrc). There is no Python/CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.y2_set_error_mode.argtypes = [C.c_int]
+    L.y2_set_error_mode(1)          # report errors as return values; this binding raises Y2Error
+    L.y2_last_error.restype = C.c_char_p
+    L.parse_network_cfg.restype = CNetwork
+    L.parse_network_cfg.argtypes = [C.c_char_p]
+    L.load_weights.argtypes = [C.POINTER(CNetwork), C.c_char_p]
+    L.load_weights_upto.argtypes = [C.POINTER(CNetwork), C.c_char_p, C.c_int]
+    L.save_weights.argtypes = [CNetwork, C.c_char_p]
+    L.set_batch_network.argtypes = [C.POINTER(CNetwork), C.c_int]
+    L.resize_network.argtypes = [C.POINTER(CNetwork), C.c_int, C.c_int]
+    L.free_network.argtypes = [CNetwork]
+    L.network_predict.restype = C.POINTER(C.c_float)
+    L.network_predict.argtypes = [CNetwork, C.c_void_p]
+    L.get_network_output.restype = C.POINTER(C.c_float)
+    L.get_network_output.argtypes = [CNetwork]
+    L.get_network_output_size.argtypes = [CNetwork]
+    L.get_network_input_size.argtypes = [CNetwork]
+    L.get_region_boxes.argtypes = [Layer, C.c_int, C.c_int, C.c_float, C.POINTER(C.POINTER(C.c_float)),
+                                   C.c_void_p, C.c_int, C.c_void_p]
+    L.do_nms_sort.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int, C.c_float]
+    L.do_nms.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.c_int, C.c_int, C.c_float]
+    L.box_iou.restype = C.c_float
+    L.box_iou.argtypes = [Box, Box]
+    L.test_detector_img.argtypes = [C.POINTER(C.c_char_p), C.c_void_p, CNetwork, Image, C.c_float,
+                                    C.POINTER(Object), C.POINTER(C.c_int)]
+    L.resize_image.restype = Image
+    L.resize_image.argtypes = [Image, C.c_int, C.c_int]
+    L.free_image.argtypes = [Image]
+    L.top_predictions.argtypes = [CNetwork, C.c_int, C.c_void_p]
+    L.cuda_set_device.argtypes = [C.c_int]
+    L.y2_prepare.argtypes = [C.POINTER(CNetwork)]
+    L.y2_set_strict.argtypes = [C.POINTER(CNetwork), C.c_int]
+    L.y2_set_timing.argtypes = [C.POINTER(CNetwork), C.c_int]
+    L.y2_layer_times_ms.argtypes = [CNetwork, C.c_void_p, C.c_int]
+    L.y2_layer_kernel.restype = C.c_char_p
+    L.y2_layer_kernel.argtypes = [CNetwork, C.c_int]
+    L.y2_weights_arena.argtypes = [C.POINTER(CNetwork), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.y2_weights_resident.argtypes = [C.POINTER(CNetwork)]
+    L.y2_network_predict_device.restype = C.POINTER(C.c_float)
+    L.y2_network_predict_device.argtypes = [CNetwork, C.c_void_p]
+    L.y2_forward_device.argtypes = [CNetwork, C.c_void_p]
+    L.y2_detect_resident.argtypes = [CNetwork, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.y2_detect.argtypes = [CNetwork, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.y2_pull_layer_output.argtypes = [CNetwork, C.c_int, C.c_void_p]
+    L.y2_stream.restype = C.c_void_p
+    L.y2_stream.argtypes = [CNetwork]
+    L.y2_sync.argtypes = [CNetwork]
+    for name in ("y2h_event_create", "y2h_event_destroy"):
+        pass
+    L.y2h_event_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.y2h_event_destroy.argtypes = [C.c_void_p]
+    L.y2h_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    L.y2h_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    L.y2h_device_count.restype = C.c_int
+    L.y2h_device_name.restype = C.c_char_p
+    L.y2h_last_error.restype = C.c_char_p
+    L.y2h_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    L.y2h_free.argtypes = [C.c_void_p]
+    L.y2h_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.y2h_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.y2h_stream_sync.argtypes = [C.c_void_p]
+    L.y2h_set_device.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+def _check():
+    L = lib()
+    msg = L.y2_last_error()
+    return msg.decode() if msg else ""
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _rows(probs: np.ndarray):
+    """float** view of a C-contiguous [total][classes] array."""
+    total = probs.shape[0]
+    arr = (C.POINTER(C.c_float) * total)()
+    base = probs.ctypes.data
+    stride = probs.strides[0]
+    for i in range(total):
+        arr[i] = C.cast(base + i * stride, C.POINTER(C.c_float))
+    return arr
+
+
+class Network:
+    """Owns a `network` struct of libsr_yolo2 (the by-value struct of the reference API)."""
+
+    def __init__(self, cnet: CNetwork):
+        self.net = cnet
+        self._freed = False
+
+    # --- parser.h ---
+    @classmethod
+    def parse_network_cfg(cls, filename: str, gpu: int = 0) -> "Network":
+        L = lib()
+        C.c_int.in_dll(L, "gpu_index").value = gpu
+        net = L.parse_network_cfg(filename.encode())
+        if not net.layers:
+            raise Y2Error("parse_network_cfg(%s): %s" % (filename, _check()))
+        return cls(net)
+
+    def load_weights(self, filename: str) -> None:
+        L = lib()
+        if not os.path.exists(filename):
+            raise Y2Error("Couldn't open file: %s" % filename)
+        L.load_weights(C.byref(self.net), filename.encode())
+
+    def save_weights(self, filename: str) -> None:
+        lib().save_weights(self.net, filename.encode())
+
+    # --- network.h ---
+    def set_batch_network(self, b: int) -> None:
+        lib().set_batch_network(C.byref(self.net), b)
+
+    def resize_network(self, w: int, h: int) -> None:
+        if lib().resize_network(C.byref(self.net), w, h) != 0:
+            raise Y2Error("resize_network: " + _check())
+
+    def network_predict(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        if x.size != self.net.batch * self.net.inputs:
+            raise ValueError("input has %d floats, network wants %d x %d" % (x.size, self.net.batch, self.net.inputs))
+        p = lib().network_predict(self.net, _ptr(x))
+        if not p:
+            raise Y2Error("network_predict: " + _check())
+        return np.ctypeslib.as_array(p, shape=(self.net.batch * self.output_size,)).copy()
+
+    @property
+    def output_size(self) -> int:
+        return lib().get_network_output_size(self.net)
+
+    @property
+    def n(self) -> int:
+        return self.net.n
+
+    @property
+    def batch(self) -> int:
+        return self.net.batch
+
+    def layer(self, i: int) -> Layer:
+        return self.net.layers[i]
+
+    @property
+    def last(self) -> Layer:
+        return self.net.layers[self.net.n - 1]
+
+    def layer_table(self):
+        rows = []
+        for i in range(self.net.n):
+            l = self.net.layers[i]
+            rows.append(dict(type=LAYER_TYPES[l.type].lower(), w=l.w, h=l.h, c=l.c, out_w=l.out_w, out_h=l.out_h,
+                             out_c=l.out_c, outputs=l.outputs, n=l.n, size=l.size, stride=l.stride, pad=l.pad,
+                             batch_normalize=l.batch_normalize, classes=l.classes, coords=l.coords))
+        return rows
+
+    # --- region_layer.h / box.h ---
+    def get_region_boxes(self, w: int, h: int, thresh: float, only_objectness: int = 0, use_map: bool = False,
+                         batch_item: int = 0, output: np.ndarray | None = None):
+        """-> (boxes[total,4], probs[total,classes]) for one batch item (the reference reads item 0:
+        region_layer.c:331; other items are reached the way Detector does it, by offsetting l.output)."""
+        L = lib()
+        l = Layer.from_buffer_copy(self.last)
+        total = l.w * l.h * l.n
+        if output is not None:
+            buf = np.ascontiguousarray(output, dtype=np.float32)
+            l.output = buf.ctypes.data_as(C.POINTER(C.c_float))
+        elif batch_item:
+            l.output = C.cast(C.addressof(l.output.contents) + batch_item * l.outputs * 4, C.POINTER(C.c_float))
+        boxes = np.zeros((total, 4), dtype=np.float32)
+        probs = np.zeros((total, l.classes), dtype=np.float32)
+        rows = _rows(probs)
+        mp = l.map if (use_map and l.map) else None
+        L.get_region_boxes(l, w, h, thresh, rows, _ptr(boxes), only_objectness, mp)
+        err = _check()
+        if L.y2_failed_and_clear():
+            raise Y2Error("get_region_boxes: " + err)
+        return boxes, probs
+
+    def test_detector_img(self, im: np.ndarray, thresh: float, names=None):
+        """im: [c][h][w] float32 -> list of dicts (x,y,w,h,prob,objClass,name,boxRGB) (detector.c:558)."""
+        L = lib()
+        im = np.ascontiguousarray(im, dtype=np.float32)
+        c, h, w = im.shape
+        cim = Image(h, w, c, im.ctypes.data_as(C.POINTER(C.c_float)))
+        objs = (Object * 2048)()
+        cnt = C.c_int(0)
+        cnames = None
+        if names:
+            cnames = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        L.test_detector_img(cnames, None, self.net, cim, thresh, objs, C.byref(cnt))
+        if L.y2_failed_and_clear():
+            raise Y2Error("test_detector_img: " + _check())
+        out = []
+        for i in range(cnt.value):
+            o = objs[i]
+            out.append(dict(x=o.x, y=o.y, w=o.w, h=o.h, prob=o.prob, objClass=o.objClass, name=o.name.decode(),
+                            boxRGB=tuple(o.boxRGB)))
+        return out
+
+    # --- extensions ---
+    def prepare(self) -> None:
+        if lib().y2_prepare(C.byref(self.net)) != 0:
+            raise Y2Error("y2_prepare: " + _check())
+
+    def set_strict(self, on: bool) -> None:
+        lib().y2_set_strict(C.byref(self.net), 1 if on else 0)
+
+    def set_timing(self, on: bool) -> None:
+        lib().y2_set_timing(C.byref(self.net), 1 if on else 0)
+
+    def layer_times_ms(self) -> np.ndarray:
+        ms = np.zeros(self.net.n, dtype=np.float32)
+        n = lib().y2_layer_times_ms(self.net, _ptr(ms), self.net.n)
+        return ms[:n]
+
+    def layer_kernel(self, i: int) -> str:
+        return lib().y2_layer_kernel(self.net, i).decode()
+
+    def weights_arena(self):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        if lib().y2_weights_arena(C.byref(self.net), C.byref(p), C.byref(n)) != 0:
+            raise Y2Error("y2_weights_arena: " + _check())
+        return p.value, n.value
+
+    def weights_resident(self) -> None:
+        lib().y2_weights_resident(C.byref(self.net))
+
+    def forward_device(self, d_input: int) -> None:
+        if lib().y2_forward_device(self.net, C.c_void_p(d_input)) != 0:
+            raise Y2Error("y2_forward_device: " + _check())
+
+    def predict_device(self, d_input: int) -> np.ndarray:
+        p = lib().y2_network_predict_device(self.net, C.c_void_p(d_input))
+        if not p:
+            raise Y2Error("y2_network_predict_device: " + _check())
+        return np.ctypeslib.as_array(p, shape=(self.net.batch * self.output_size,)).copy()
+
+    def detect_resident(self, thresh: float, nms: float, img_w: int = 1, img_h: int = 1, max_per_image: int | None = None):
+        l = self.last
+        cap = max_per_image or (l.w * l.h * l.n)
+        dets = np.zeros((self.net.batch, cap), dtype=DET_DTYPE)
+        counts = np.zeros(self.net.batch, dtype=np.int32)
+        if lib().y2_detect_resident(self.net, thresh, nms, img_w, img_h, _ptr(dets), _ptr(counts), cap) != 0:
+            raise Y2Error("y2_detect_resident: " + _check())
+        return [dets[b, :min(int(counts[b]), cap)].copy() for b in range(self.net.batch)], counts
+
+    def detect(self, x: np.ndarray, thresh: float, nms: float, img_w: int = 1, img_h: int = 1):
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        l = self.last
+        cap = l.w * l.h * l.n
+        dets = np.zeros((self.net.batch, cap), dtype=DET_DTYPE)
+        counts = np.zeros(self.net.batch, dtype=np.int32)
+        if lib().y2_detect(self.net, _ptr(x), thresh, nms, img_w, img_h, _ptr(dets), _ptr(counts), cap) != 0:
+            raise Y2Error("y2_detect: " + _check())
+        return [dets[b, :min(int(counts[b]), cap)].copy() for b in range(self.net.batch)], counts
+
+    def pull_layer_output(self, i: int) -> np.ndarray:
+        l = self.net.layers[i]
+        out = np.zeros(self.net.batch * l.outputs, dtype=np.float32)
+        if lib().y2_pull_layer_output(self.net, i, _ptr(out)) != 0:
+            raise Y2Error("y2_pull_layer_output: " + _check())
+        return out
+
+    def sync(self) -> None:
+        lib().y2_sync(self.net)
+
+    def stream(self) -> int:
+        return lib().y2_stream(self.net) or 0
+
+    def free(self) -> None:
+        if not self._freed:
+            lib().free_network(self.net)
+            self._freed = True
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def do_nms_sort(boxes: np.ndarray, probs: np.ndarray, thresh: float, classes: int | None = None) -> np.ndarray:
+    """box.c:249 on host arrays (staged through the GPU kernel).  Returns the updated probs."""
+    L = lib()
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    probs = np.array(probs, dtype=np.float32, order="C", copy=True)
+    L.do_nms_sort(_ptr(boxes), _rows(probs), probs.shape[0], classes or probs.shape[1], thresh)
+    if L.y2_failed_and_clear():
+        raise Y2Error("do_nms_sort: " + _check())
+    return probs
+
+
+def do_nms(boxes: np.ndarray, probs: np.ndarray, thresh: float) -> np.ndarray:
+    L = lib()
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    probs = np.array(probs, dtype=np.float32, order="C", copy=True)
+    L.do_nms(_ptr(boxes), _rows(probs), probs.shape[0], probs.shape[1], thresh)
+    if L.y2_failed_and_clear():
+        raise Y2Error("do_nms: " + _check())
+    return probs
+
+
+def box_iou(a, b) -> float:
+    return float(lib().box_iou(Box(*[float(v) for v in a]), Box(*[float(v) for v in b])))
+
+
+def resize_image(im: np.ndarray, w: int, h: int) -> np.ndarray:
+    """image.c:1950 on the GPU: [c][ih][iw] -> [c][h][w]."""
+    L = lib()
+    im = np.ascontiguousarray(im, dtype=np.float32)
+    c, ih, iw = im.shape
+    out = L.resize_image(Image(ih, iw, c, im.ctypes.data_as(C.POINTER(C.c_float))), w, h)
+    if L.y2_failed_and_clear():
+        raise Y2Error("resize_image: " + _check())
+    arr = np.ctypeslib.as_array(out.data, shape=(c, h, w)).copy()
+    L.free_image(out)
+    return arr
+
+
+def device_count() -> int:
+    return int(lib().y2h_device_count())
+
+
+def device_name() -> str:
+    return lib().y2h_device_name().decode()

@@ -68,7 +68,17 @@ SPECS = {
     ],
 }
 
-DEFAULT_SIZE = {"yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32}
+# same topology with channel counts the matrix-core kernels take (Cin % 16 == 0 after the first layer):
+# exercises BK=16 and BK=32 slices, 128/64/32-filter tiles, a placed (zero-copy) concat and the edge tiles
+SPECS["mini-mfma"] = [
+    ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("conv", 32, 3, 1, "leaky"), ("conv", 16, 1, 1, "leaky"),
+    ("conv", 64, 3, 1, "leaky"), ("max", 2, 2), ("conv", 128, 3, 1, "leaky"), ("max", 2, 1),
+    ("conv", 160, 3, 1, "leaky"), ("route", [-5]), ("conv", 16, 1, 1, "leaky"), ("reorg", 2),
+    ("route", [-1, -4]), ("conv", 96, 3, 1, "leaky"), ("conv", 30, 1, 0, "linear"),
+    ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]}),
+]
+
+DEFAULT_SIZE = {"yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64}
 
 
 def cfg_text(name: str, width: int | None = None, height: int | None = None, batch: int = 1,

@@ -38,6 +38,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 CASES = [
     ("mini_32_b2", "mini", 32, 2, 11, 0.6, 0.4, 4.0),
     ("mini_64_b3", "mini", 64, 3, 12, 0.7, 0.4, 4.0),
+    ("mini_mfma_64_b2", "mini-mfma", 64, 2, 7, 0.5, 0.4, 4.0),
     ("tiny_yolo_voc_416_b1", "tiny-yolo-voc", 416, 1, 21, 0.2, 0.4, 4.0),
     ("tiny_yolo_voc_416_b1_kinect", "tiny-yolo-voc", 416, 1, 21, 0.24, 0.1, 4.0),
     ("yolo_416_b1", "yolo", 416, 1, 31, 0.2, 0.4, 4.0),
@@ -163,6 +164,10 @@ def generate_case(name, net, size, batch, seed, thresh, nms, gain, use_map):
                     fix["post_idx_%d" % b] = np.stack([r, c], 1).astype(np.int32)
                     fix["post_val_%d" % b] = post[r, c]
                     fix["margins_%d" % b] = np.array([mt, mi, mtie])
+                n_pre = sum(len(fix["pre_val_%d" % b]) for b in range(batch))
+                n_post = sum(len(fix["post_val_%d" % b]) for b in range(batch))
+                if net != "yolo9000" and (n_pre < 8 or (nms > 0 and n_post >= n_pre)):
+                    return False              # too few detections / no suppression: a weak NMS test
             path = os.path.join(OUT, name + ".npz")
             np.savez_compressed(path, **fix)
             print("%s: out[%d] sum=%.6f  ref predict %.2fs -> %s (%d KB)" % (

@@ -1,0 +1,213 @@
+"""GPU parity: the HIP engine, called through the C-ABI library, against the CPU
+oracle and against the golden vectors the compiled reference produced.
+
+Tolerances (BASELINE.json north_star): region-layer tensor, box coordinates and
+probabilities within 1e-4 absolute of the CPU path; post-NMS detection sets
+identical (same (box, class) survivors, so identical counts).  In strict mode
+(reference-order VALU convolution) everything must be bit-identical."""
+import numpy as np
+import pytest
+
+from sr_object_detection_amd import darknet
+from tests.helpers import dense_from_sparse, load_golden, materialize
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+CASES = ["mini_32_b2", "mini_64_b3", "mini_mfma_64_b2", "tiny_yolo_voc_416_b1", "tiny_yolo_voc_416_b1_kinect",
+         "yolo_416_b1", "yolo_608_b1"]
+
+
+def run_case(workdir, name, strict=False):
+    g = load_golden(name)
+    net_name, size, batch, seed = str(g["net"]), int(g["size"]), int(g["batch"]), int(g["seed"])
+    thresh, nms, gain = float(g["thresh"]), float(g["nms"]), float(g["head_gain"])
+    cfg, wts, x = materialize(workdir, net_name, size, batch, seed, gain)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    if strict:
+        net.set_strict(True)
+    out = net.network_predict(x)
+    return g, net, x, out, thresh, nms
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_matches_reference_golden(workdir, name):
+    g, net, x, out, thresh, nms = run_case(workdir, name)
+    ref = g["out"]
+    assert out.shape == ref.shape
+    err = np.abs(out - ref)
+    # tw/th are raw logits fed to exp(); compare everything absolutely, as the north star states
+    assert float(err.max()) < TOL, "max |gpu - reference| = %g at %d" % (err.max(), int(err.argmax()))
+    kernels = [net.layer_kernel(i) for i in range(net.n)]
+    if name.startswith(("yolo", "tiny", "mini_mfma")):
+        assert any(k.startswith("conv_mfma_f32") for k in kernels), kernels
+    net.free()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_decode_and_nms_match_reference_golden(workdir, name):
+    g, net, x, out, thresh, nms = run_case(workdir, name)
+    batch = int(g["batch"])
+    l = net.last
+    total, classes = l.w * l.h * l.n, l.classes
+    dets, counts = net.detect_resident(thresh, nms)
+    for b in range(batch):
+        boxes, probs = net.get_region_boxes(1, 1, thresh, batch_item=b)
+        assert np.abs(boxes - g["boxes_%d" % b]).max() < TOL
+        pre = dense_from_sparse(g["pre_idx_%d" % b], g["pre_val_%d" % b], total, classes)
+        assert np.array_equal(probs > 0, pre > 0), "different set of (box, class) pairs above thresh"
+        assert np.abs(probs - pre).max() < TOL
+        post = darknet.do_nms_sort(boxes, probs, nms)
+        gpost = dense_from_sparse(g["post_idx_%d" % b], g["post_val_%d" % b], total, classes)
+        assert np.array_equal(post > 0, gpost > 0), "NMS kept a different set"
+        assert int((post > 0).sum()) == len(g["post_val_%d" % b])
+        assert np.abs(post - gpost).max() < TOL
+        # fused resident path: same survivors, in ascending box order
+        keep = np.nonzero(gpost.max(axis=1) > thresh)[0]
+        assert int(counts[b]) == keep.size
+        d = dets[b]
+        assert np.array_equal(d["obj_id"], gpost[keep].argmax(axis=1))
+        assert np.abs(d["prob"] - gpost[keep].max(axis=1)).max() < TOL
+        got = np.stack([d["x"], d["y"], d["w"], d["h"]], 1)
+        assert np.abs(got - g["boxes_%d" % b][keep]).max() < TOL
+    net.free()
+
+
+@pytest.mark.parametrize("name", ["mini_32_b2", "mini_mfma_64_b2", "tiny_yolo_voc_416_b1"])
+def test_strict_mode_is_bit_identical_to_reference(workdir, name):
+    """With the reference-order VALU convolution every layer, the decode and the NMS are bit-exact."""
+    g, net, x, out, thresh, nms = run_case(workdir, name, strict=True)
+    assert all(net.layer_kernel(i) == "conv_direct_f32" for i in range(net.n)
+               if darknet.LAYER_TYPES[net.layer(i).type] == "CONVOLUTIONAL")
+    assert np.array_equal(out, g["out"])
+    l = net.last
+    total, classes = l.w * l.h * l.n, l.classes
+    for b in range(int(g["batch"])):
+        boxes, probs = net.get_region_boxes(1, 1, thresh, batch_item=b)
+        assert np.array_equal(boxes, g["boxes_%d" % b])
+        assert np.array_equal(probs, dense_from_sparse(g["pre_idx_%d" % b], g["pre_val_%d" % b], total, classes))
+        post = darknet.do_nms_sort(boxes, probs, nms)
+        assert np.array_equal(post, dense_from_sparse(g["post_idx_%d" % b], g["post_val_%d" % b], total, classes))
+    net.free()
+
+
+@pytest.mark.parametrize("name,size,batch", [("mini-mfma", 64, 2), ("mini-mfma", 96, 3), ("tiny-yolo-voc", 416, 2)])
+def test_every_layer_against_oracle(oracle, workdir, name, size, batch):
+    """Layer-by-layer comparison with the CPU oracle on the same seeded inputs (NCHW on both sides)."""
+    cfg, wts, x = materialize(workdir, name, size, batch, 77)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    out = net.network_predict(x)
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    for i in range(net.n):
+        got = net.pull_layer_output(i)
+        want = on.layer_output(i)
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(got - want).max() < TOL * scale, "layer %d (%s) differs" % (i, net.layer_kernel(i))
+    assert np.abs(out - ref).max() < TOL
+    net.free()
+    on.close()
+
+
+def test_batch_items_are_independent_and_batch_can_change(oracle, workdir):
+    """Frame sharding relies on this: an image's result does not depend on its batch mates,
+    and set_batch_network may shrink or grow the batch (re-planned lazily)."""
+    cfg, wts, x = materialize(workdir, "mini-mfma", 64, 4, 5)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    full = net.network_predict(x).reshape(4, -1)
+    net.set_batch_network(1)
+    for b in (0, 3):
+        one = net.network_predict(x[b])
+        assert np.array_equal(one, full[b])
+    net.set_batch_network(6)                         # larger than the cfg's batch: the reference would overflow
+    x6 = np.concatenate([x, x[:2]], 0)
+    six = net.network_predict(x6).reshape(6, -1)
+    assert np.array_equal(six[:4], full) and np.array_equal(six[4:], full[:2])
+    net.free()
+
+
+def test_resize_network_matches_oracle(oracle, workdir):
+    cfg416, wts, _ = materialize(workdir, "tiny-yolo-voc", 416, 1, 9)
+    cfg288, _, x = materialize(workdir, "tiny-yolo-voc", 288, 1, 9)
+    net = darknet.Network.parse_network_cfg(cfg416)
+    net.load_weights(wts)
+    net.resize_network(288, 288)
+    out = net.network_predict(x)
+    on = oracle.OracleNet(cfg288, wts)
+    assert np.abs(out - on.predict(x)).max() < TOL
+    net.free()
+    on.close()
+
+
+def test_darknet19_classifier(oracle, workdir):
+    g = load_golden("darknet19_224_b1")
+    cfg, wts, x = materialize(workdir, "darknet19", 224, 1, int(g["seed"]), float(g["head_gain"]))
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    out = net.network_predict(x)
+    assert out.shape == (1000,)
+    assert np.abs(out - g["out"]).max() < TOL
+    assert list(oracle.top_k(out, 5)) == list(oracle.top_k(g["out"], 5))
+    net.free()
+
+
+@pytest.mark.parametrize("name", ["yolo9000_96_b1", "yolo9000_96_b1_map"])
+def test_yolo9000_tree_head(workdir, name):
+    g = load_golden(name)
+    use_map = bool(int(g["use_map"]))
+    cfg, wts, x = materialize(workdir, "yolo9000", int(g["size"]), 1, int(g["seed"]), float(g["head_gain"]), use_map)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    out = net.network_predict(x)
+    if not use_map:
+        assert np.abs(out - g["out"]).max() < TOL
+    thresh, nms = float(g["thresh"]), float(g["nms"])
+    l = net.last
+    total, classes = l.w * l.h * l.n, l.classes
+    boxes, probs = net.get_region_boxes(1, 1, thresh, use_map=use_map)
+    assert np.abs(boxes - g["boxes_0"]).max() < TOL
+    pre = dense_from_sparse(g["pre_idx_0"], g["pre_val_0"], total, classes)
+    assert np.array_equal(probs > 0, pre > 0)
+    assert np.abs(probs - pre).max() < TOL
+    ncls = 200 if use_map else classes
+    post = probs.copy()
+    post[:, :ncls] = darknet.do_nms_sort(boxes, np.ascontiguousarray(probs[:, :ncls]), nms)
+    gpost = dense_from_sparse(g["post_idx_0"], g["post_val_0"], total, classes)
+    assert np.array_equal(post > 0, gpost > 0)
+    net.free()
+
+
+def test_detector_hand_off_matches_oracle(oracle, workdir):
+    """test_detector_img (detector.c:558: resize -> predict -> decode -> nms 0.1 -> objects) end to end,
+    including the 4-plane BGRA quirk (only the first 3 planes are read) and a resize."""
+    g = load_golden("tiny_yolo_voc_416_b1_kinect")
+    cfg, wts, x = materialize(workdir, "tiny-yolo-voc", 416, 1, int(g["seed"]), float(g["head_gain"]))
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    thresh = float(g["thresh"])
+    im4 = np.concatenate([x[0], np.full((1, 416, 416), 0.5, np.float32)], 0)     # B,G,R,A planes
+    objs = net.test_detector_img(im4, thresh)
+    total, classes = net.last.w * net.last.h * net.last.n, net.last.classes
+    gpost = dense_from_sparse(g["post_idx_0"], g["post_val_0"], total, classes)
+    want = oracle.test_detector_objects(g["boxes_0"], gpost, thresh)
+    assert len(objs) == len(want) > 0
+    for o, w in zip(objs, want):
+        assert o["objClass"] == int(w[5])
+        assert abs(o["prob"] - w[4]) < TOL and max(abs(o[k] - w[j]) for j, k in enumerate("xywh")) < TOL
+        assert np.allclose(o["boxRGB"], w[6:9], atol=0)
+    # a frame of another size goes through the device resize (image.c:1950)
+    small = oracle.resize_image(x[0], 320, 240)
+    sized = oracle.resize_image(small, 416, 416)
+    on = oracle.OracleNet(cfg, wts)
+    on.predict(sized)
+    boxes, probs = on.region_boxes(0, thresh)
+    post = oracle.do_nms_sort(boxes, probs, 0.1)
+    want2 = oracle.test_detector_objects(boxes, post, thresh)
+    objs2 = net.test_detector_img(small, thresh)
+    assert len(objs2) == len(want2)
+    net.free()
+    on.close()
