@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the YOLOv2 (yolo.cfg) forward path at 608x608, fp32, on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic frames that are
+already resident in HBM: NCHW->NHWC, 23 convolutions (+BN/bias/leaky), 5 maxpools,
+route/reorg, region head, box decode, per-class NMS and compaction of the detections,
+ending with the small D2H copy of the compact detection records
+(y2_forward_device + y2_detect_resident of libsr_yolo2.so).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: one process per GPU; rank 0 loads the weights, packs them into the
+kernel-layout arena and the arena is replicated with ONE RCCL broadcast
+(torch.distributed, backend "nccl"); every rank then runs its own frame batch
+(weak scaling, no per-step collective).  Timing = K steps between barriers, MAX over ranks.
+
+Rank 0 prints one JSON line (see DESIGN.md section "Measurement"): value, roofline
+of the dominant kernel from HIP-event timings taken inside the timed region, and the
+CPU baseline (the reference's own CPU path compiled into oracle/_ref when present,
+otherwise the oracle port) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from sr_object_detection_amd import darknet, synth, zoo  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: the configuration the metric (608x608 fp32) is quoted on
+    "yolo608_b32": dict(net="yolo", size=608, batch=32),
+    # configs[1]
+    "yolo416_b8": dict(net="yolo", size=416, batch=8),
+    "tiny416_b1": dict(net="tiny-yolo-voc", size=416, batch=1),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
+THRESH, NMS = 0.2, 0.4             # Detector defaults (yolo_v2_class.hpp:45,50)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="yolo608_b32", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-iters", type=int, default=2, help="timed CPU-baseline forwards (0 disables the leg)")
+    ap.add_argument("--seed", type=int, default=31)
+    return ap.parse_args()
+
+
+def conv_layer_flops(net):
+    """2*M*N*K per conv layer and image (src_yolo2/darknet.c:115-131), indexed by layer."""
+    out = {}
+    for i in range(net.n):
+        l = net.layer(i)
+        if darknet.LAYER_TYPES[l.type] == "CONVOLUTIONAL":
+            out[i] = 2.0 * l.n * l.size * l.size * l.c * l.out_h * l.out_w
+    return out
+
+
+def cpu_baseline(cfg_b1: str, wts: str, size: int, iters: int, tmp: str):
+    """The reference CPU path on this host's cores, batch 1 (the reference's own mode), wall clock."""
+    if iters <= 0:
+        return None
+    cores = len(os.sched_getaffinity(0))
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+    ref_driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    t0 = time.time()
+    if os.path.exists(ref_driver):
+        try:
+            out = subprocess.run([ref_driver, "time", cfg_b1, wts, str(iters)], env=env, capture_output=True,
+                                 text=True, timeout=600, check=True).stdout.strip().splitlines()[-1]
+            r = json.loads(out)
+            return dict(value=round(1.0 / r["mean_s"], 4), unit="images/sec", cores=cores, kind="reference",
+                        sample="%d forwards of yolo.cfg %dx%d batch 1 (network_predict only, after 1 warm-up) by the "
+                               "reference's own C sources built -O2 -fopenmp; %.1f s of CPU work" % (
+                                   iters, size, size, time.time() - t0))
+        except Exception as e:      # fall through to the port
+            sys.stderr.write("cpu_baseline: reference driver failed (%s); using the oracle port\n" % e)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    from oracle import oracle_capi
+    on = oracle_capi.OracleNet(cfg_b1, wts)
+    x = synth.image_batch(1, 3, size, size)
+    secs = on.time_predict(x, iters)
+    on.close()
+    return dict(value=round(iters / secs, 4), unit="images/sec", cores=cores, kind="port",
+                sample="%d forwards of yolo.cfg %dx%d batch 1 (predict only, after 1 warm-up) by oracle/y2_oracle.c; "
+                       "%.1f s of CPU work" % (iters, size, size, time.time() - t0))
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        sys.stderr.write("bench: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    name, size, batch = wl["net"], wl["size"], wl["batch"]
+    tmp = tempfile.mkdtemp(prefix="y2bench_r%d_" % rank)
+    cfg = os.path.join(tmp, "net.cfg")
+    open(cfg, "w").write(zoo.cfg_text(name, size, size, batch))
+    layers = zoo.resolve(name, size)
+
+    L = darknet.lib()
+    net = darknet.Network.parse_network_cfg(cfg, gpu=local_rank)
+    wts = os.path.join(tmp, "net.weights")
+    if rank == 0:
+        synth.write_weights(wts, layers, args.seed)
+        net.load_weights(wts)
+        net.prepare()
+    arena_ptr, arena_bytes = net.weights_arena()
+    if world > 1:
+        # replicate the packed weights: ONE broadcast of the kernel-layout arena over RCCL/xGMI
+        buf = torch.empty(arena_bytes, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            assert L.y2h_memcpy_d2d(buf.data_ptr(), arena_ptr, arena_bytes, None) == 0
+            L.y2h_device_sync()
+        dist.broadcast(buf, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            assert L.y2h_memcpy_d2d(arena_ptr, buf.data_ptr(), arena_bytes, None) == 0
+            L.y2h_device_sync()
+            net.weights_resident()
+        del buf
+
+    # this rank's frames: global image index = rank*batch + i, resident in HBM before timing starts
+    x = synth.image_batch(batch, 3, size, size, seed=0xC0FFEE + rank * batch)
+    d_x = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+
+    def step():
+        net.forward_device(d_x.data_ptr())
+        return net.detect_resident(THRESH, NMS)
+
+    for _ in range(args.warmup):
+        dets, counts = step()
+    net.set_timing(True)
+    flops = conv_layer_flops(net)
+    kernels = {i: net.layer_kernel(i) for i in range(net.n)}
+    per_kernel_ms = {}
+    per_kernel_flops = {}
+    per_kernel_launches = {}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dets, counts = step()
+        ms = net.layer_times_ms()          # HIP events recorded on the engine's stream around every layer
+        for i, k in kernels.items():
+            if i in flops and i < len(ms):
+                per_kernel_ms[k] = per_kernel_ms.get(k, 0.0) + float(ms[i])
+                per_kernel_flops[k] = per_kernel_flops.get(k, 0.0) + flops[i] * batch
+                per_kernel_launches[k] = per_kernel_launches.get(k, 0) + 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_images = world * batch * args.steps
+        dom = max(per_kernel_ms, key=lambda k: per_kernel_ms[k]) if per_kernel_ms else None
+        roof = None
+        if dom:
+            ach = per_kernel_flops[dom] / (per_kernel_ms[dom] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        launches_per_step=per_kernel_launches[dom] // max(args.steps, 1),
+                        avg_launch_ms=round(per_kernel_ms[dom] / per_kernel_launches[dom], 4),
+                        avg_launch_gflop=round(per_kernel_flops[dom] / per_kernel_launches[dom] / 1e9, 3))
+        conv_ms = sum(per_kernel_ms.values()) / max(args.steps, 1)
+        cfg_b1 = os.path.join(tmp, "net_b1.cfg")
+        open(cfg_b1, "w").write(zoo.cfg_text(name, size, size, 1))
+        cpu = cpu_baseline(cfg_b1, wts, size, args.cpu_iters, tmp)
+        line = {
+            "metric": "images/sec YOLOv2 608x608 fp32" if size == 608 else "images/sec YOLOv2 %dx%d fp32" % (size, size),
+            "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d batch %d per GPU: forward + region decode + NMS(%.1f) + collect, "
+                                   "inputs resident in HBM" % (name + ".cfg", size, size, batch, NMS),
+                       "global_batch": batch * world, "parallelism": "frame-sharded x%d (RCCL weight broadcast)" % world,
+                       "gflop_per_image": round(zoo.conv_flops(layers) / 1e9, 3),
+                       "conv_ms_per_step": round(conv_ms, 3),
+                       "detections_in_last_batch": int(np.sum(counts))},
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernels_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in sorted(per_kernel_ms.items())},
+            "device": darknet.device_name(),
+        }
+        print(json.dumps(line))
+        sys.stdout.flush()
+    net.free()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,9 +147,12 @@ typedef struct y2h_decode {
 int y2h_region_boxes(const y2h_decode *d, y2h_stream s);
 
 /* per-class sort + greedy suppression on device arrays, box.c:249-277.
- * probs rows have `stride` floats; only the first `classes` columns take part. */
-int y2h_nms_sort(const float *boxes, float *probs, int batch, int total, int classes, int stride,
-                 float thresh, y2h_stream s);
+ * probs rows have `stride` floats; only the first `classes` columns take part.
+ * `probs_in` holds the scores and is only read (the tie order of the reference's
+ * repeated stable sort depends on the original scores of earlier classes);
+ * `probs` must be a separate copy of it, in which suppressed scores are zeroed. */
+int y2h_nms_sort(const float *boxes, const float *probs_in, float *probs, int batch, int total, int classes,
+                 int stride, float thresh, y2h_stream s);
 /* class-agnostic variant, box.c:279-298 */
 int y2h_nms(const float *boxes, float *probs, int batch, int total, int classes, int stride,
             float thresh, y2h_stream s);

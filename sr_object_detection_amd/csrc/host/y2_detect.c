@@ -77,7 +77,7 @@ void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *b
 }
 
 /* scratch for the array-in/array-out NMS entry points (not thread-safe, like the reference) */
-static struct { float *d_boxes, *d_probs; size_t boxes_cap, probs_cap; y2h_stream stream; int device; } g_nms = {0, 0, 0, 0, 0, -1};
+static struct { float *d_boxes, *d_probs, *d_probs_in; size_t boxes_cap, probs_cap; y2h_stream stream; int device; } g_nms = {0, 0, 0, 0, 0, 0, -1};
 
 static int nms_scratch(size_t nboxes, size_t nprobs)
 {
@@ -85,12 +85,17 @@ static int nms_scratch(size_t nboxes, size_t nprobs)
     if (y2h_device_count() <= 0) { y2_fail("do_nms: no HIP device visible and this library has no CPU path"); return -1; }
     HIPCALL_I(y2h_get_device(&dev));
     if (g_nms.device != dev) {
-        g_nms.d_boxes = g_nms.d_probs = NULL; g_nms.boxes_cap = g_nms.probs_cap = 0; g_nms.stream = NULL;   /* per-device scratch */
+        g_nms.d_boxes = g_nms.d_probs = g_nms.d_probs_in = NULL; g_nms.boxes_cap = g_nms.probs_cap = 0; g_nms.stream = NULL;   /* per-device scratch */
         g_nms.device = dev;
     }
     if (!g_nms.stream) HIPCALL_I(y2h_stream_create(&g_nms.stream));
     if (nboxes > g_nms.boxes_cap) { y2h_free(g_nms.d_boxes); HIPCALL_I(y2h_malloc((void **)&g_nms.d_boxes, nboxes * sizeof(float))); g_nms.boxes_cap = nboxes; }
-    if (nprobs > g_nms.probs_cap) { y2h_free(g_nms.d_probs); HIPCALL_I(y2h_malloc((void **)&g_nms.d_probs, nprobs * sizeof(float))); g_nms.probs_cap = nprobs; }
+    if (nprobs > g_nms.probs_cap) {
+        y2h_free(g_nms.d_probs); y2h_free(g_nms.d_probs_in);
+        HIPCALL_I(y2h_malloc((void **)&g_nms.d_probs, nprobs * sizeof(float)));
+        HIPCALL_I(y2h_malloc((void **)&g_nms.d_probs_in, nprobs * sizeof(float)));
+        g_nms.probs_cap = nprobs;
+    }
     return 0;
 }
 
@@ -104,7 +109,10 @@ static void nms_host(box *boxes, float **probs, int total, int classes, float th
     for (i = 0; i < total; ++i) memcpy(flat + (size_t)i * classes, probs[i], classes * sizeof(float));
     HIPCALL(y2h_memcpy_h2d(g_nms.d_boxes, boxes, (size_t)total * sizeof(box), g_nms.stream));
     HIPCALL(y2h_memcpy_h2d(g_nms.d_probs, flat, (size_t)total * classes * sizeof(float), g_nms.stream));
-    if (sorted) HIPCALL(y2h_nms_sort(g_nms.d_boxes, g_nms.d_probs, 1, total, classes, classes, thresh, g_nms.stream));
+    if (sorted) {
+        HIPCALL(y2h_memcpy_d2d(g_nms.d_probs_in, g_nms.d_probs, (size_t)total * classes * sizeof(float), g_nms.stream));
+        HIPCALL(y2h_nms_sort(g_nms.d_boxes, g_nms.d_probs_in, g_nms.d_probs, 1, total, classes, classes, thresh, g_nms.stream));
+    }
     else HIPCALL(y2h_nms(g_nms.d_boxes, g_nms.d_probs, 1, total, classes, classes, thresh, g_nms.stream));
     HIPCALL(y2h_memcpy_d2h(flat, g_nms.d_probs, (size_t)total * classes * sizeof(float), g_nms.stream));
     HIPCALL(y2h_stream_sync(g_nms.stream));
@@ -209,6 +217,7 @@ int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_
     layer *l;
     y2_ldev *d;
     y2h_decode q;
+    const float *final_probs;
     int b, i, keep;
     if (!e || !e->built) { y2_fail("y2_detect_resident: run a forward first"); return -1; }
     l = &net.layers[e->out_layer];
@@ -222,9 +231,13 @@ int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_
     q.tree_parent = l->softmax_tree ? d->d_tree_parent : NULL;
     q.pred = d->d_region; q.boxes = e->d_boxes; q.probs = e->d_probs;
     HIPCALL_I(y2h_region_boxes(&q, e->stream));
-    if (nms > 0)
-        HIPCALL_I(y2h_nms_sort(e->d_boxes, e->d_probs, net.batch, e->det_total, l->classes, l->classes, nms, e->stream));
-    HIPCALL_I(y2h_collect(e->d_boxes, e->d_probs, net.batch, e->det_total, l->classes, l->classes, thresh,
+    final_probs = e->d_probs;
+    if (nms > 0) {
+        HIPCALL_I(y2h_memcpy_d2d(e->d_probs_nms, e->d_probs, (size_t)net.batch * e->det_total * l->classes * sizeof(float), e->stream));
+        HIPCALL_I(y2h_nms_sort(e->d_boxes, e->d_probs, e->d_probs_nms, net.batch, e->det_total, l->classes, l->classes, nms, e->stream));
+        final_probs = e->d_probs_nms;
+    }
+    HIPCALL_I(y2h_collect(e->d_boxes, final_probs, net.batch, e->det_total, l->classes, l->classes, thresh,
                           e->d_records, e->d_counts, e->det_cap, e->stream));
     HIPCALL_I(y2h_memcpy_d2h(e->h_counts, e->d_counts, (size_t)net.batch * sizeof(int), e->stream));
     HIPCALL_I(y2h_stream_sync(e->stream));

@@ -74,6 +74,7 @@ static void free_plan(network *net)
     y2h_host_free(e->h_out); e->h_out = NULL;
     y2h_free(e->d_boxes); e->d_boxes = NULL;
     y2h_free(e->d_probs); e->d_probs = NULL;
+    y2h_free(e->d_probs_nms); e->d_probs_nms = NULL;
     y2h_free(e->d_records); e->d_records = NULL;
     y2h_free(e->d_counts); e->d_counts = NULL;
     y2h_host_free(e->h_records); e->h_records = NULL;
@@ -317,6 +318,7 @@ int y2_engine_build(network *net)
             e->det_cap = e->det_total;
             HIPCALL(y2h_malloc((void **)&e->d_boxes, (size_t)net->batch * e->det_total * 4 * sizeof(float)));
             HIPCALL(y2h_malloc((void **)&e->d_probs, (size_t)net->batch * e->det_total * ol->classes * sizeof(float)));
+            HIPCALL(y2h_malloc((void **)&e->d_probs_nms, (size_t)net->batch * e->det_total * ol->classes * sizeof(float)));
             HIPCALL(y2h_malloc((void **)&e->d_records, (size_t)net->batch * e->det_cap * 6 * sizeof(float)));
             HIPCALL(y2h_malloc((void **)&e->d_counts, (size_t)net->batch * sizeof(int)));
             HIPCALL(y2h_host_alloc((void **)&e->h_records, (size_t)net->batch * e->det_cap * 6 * sizeof(float)));

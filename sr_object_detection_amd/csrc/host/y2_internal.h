@@ -53,7 +53,7 @@ typedef struct y2_engine {
     size_t out_floats;
     int out_layer;
     /* decode / nms buffers for the output region layer */
-    float *d_boxes, *d_probs, *d_records;
+    float *d_boxes, *d_probs, *d_probs_nms, *d_records;
     int *d_counts;
     float *h_records;
     int *h_counts;

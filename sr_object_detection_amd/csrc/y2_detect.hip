@@ -146,7 +146,27 @@ __device__ __forceinline__ float box_iou_f(float4 a, float4 b)
 // Zero scores never act and zeroing them again is a no-op, so restricting the
 // sort to non-zero scores is exactly the reference's result.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__ boxes, float *__restrict__ probs,
+//
+// Ties: the reference sorts ONE array again and again (box.c:252-264), so boxes
+// with equal score in class k keep the order the class k-1 sort left, i.e. the
+// order is lexicographic over (p_k, p_{k-1}, ..., p_0) descending, then box
+// index ascending (with a stable qsort, as glibc's is).  Each class's scores
+// are only changed by that class's own suppression, after its sort, so the
+// tie-break reads the ORIGINAL scores: `pin` is never written here and the
+// survivors go to `pout` (a copy of pin made by the caller).  Runs of equal
+// keys are rare; each is re-ordered by one lane after the bitonic sort.
+__device__ __forceinline__ bool tie_before(const float *pin, int stride, int k, unsigned ia, unsigned ib)
+{
+    for (int c = k - 1; c >= 0; --c) {
+        const float pa = pin[(size_t)ia * stride + c], pb = pin[(size_t)ib * stride + c];
+        if (pa > pb) return true;
+        if (pa < pb) return false;
+    }
+    return ia < ib;
+}
+
+__global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ pin_all,
+                                                       float *__restrict__ pout_all,
                                                        int total, int classes, int stride, float thresh, int cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
@@ -157,7 +177,8 @@ __global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__
     const int k = blockIdx.x % classes;
     const int b = blockIdx.x / classes;
     const float *bx = boxes + (size_t)b * total * 4;
-    float *pr = probs + (size_t)b * total * stride;
+    const float *pr = pin_all + (size_t)b * total * stride;
+    float *pw = pout_all + (size_t)b * total * stride;
     const int t = threadIdx.x;
 
     if (t == 0) s_count = 0;
@@ -191,6 +212,26 @@ __global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__
             __syncthreads();
         }
     }
+    // re-order runs of equal scores the way the reference's repeated stable sort does
+    for (int i = t; i < n - 1; i += 256) {
+        const unsigned pi = (unsigned)(keys[i] >> 32);
+        const bool starts = (i == 0 || (unsigned)(keys[i - 1] >> 32) != pi) && (unsigned)(keys[i + 1] >> 32) == pi;
+        if (starts && k > 0) {
+            int e = i + 1;
+            while (e < n && (unsigned)(keys[e] >> 32) == pi) ++e;
+            for (int a = i + 1; a < e; ++a) {                 // insertion sort of the run [i, e)
+                const unsigned long long ka = keys[a];
+                const unsigned ia = ~(unsigned)(ka & 0xffffffffull);
+                int j = a - 1;
+                while (j >= i && tie_before(pr, stride, k, ia, ~(unsigned)(keys[j] & 0xffffffffull))) {
+                    keys[j + 1] = keys[j];
+                    --j;
+                }
+                keys[j + 1] = ka;
+            }
+        }
+    }
+    __syncthreads();
     // greedy suppression in sorted order
     for (int i = 0; i < n - 1; ++i) {
         if (!dead[i]) {                      // uniform: every lane reads the same LDS byte
@@ -207,14 +248,15 @@ __global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__
     for (int j = t; j < n; j += 256)
         if (dead[j]) {
             const unsigned ib = ~(unsigned)(keys[j] & 0xffffffffull);
-            pr[(size_t)ib * stride + k] = 0;
+            pw[(size_t)ib * stride + k] = 0;
         }
 }
 
-extern "C" int y2h_nms_sort(const float *boxes, float *probs, int batch, int total, int classes, int stride,
-                            float thresh, y2h_stream s)
+extern "C" int y2h_nms_sort(const float *boxes, const float *probs_in, float *probs, int batch, int total, int classes,
+                            int stride, float thresh, y2h_stream s)
 {
-    if (!boxes || !probs || batch <= 0 || total <= 0 || classes <= 0 || stride < classes) return Y2H_EINVAL;
+    if (!boxes || !probs || !probs_in || probs == probs_in || batch <= 0 || total <= 0 || classes <= 0 || stride < classes)
+        return Y2H_EINVAL;
     if (total > 16384) return Y2H_EINVAL;            // LDS holds every candidate of one class
     int cap = 1;
     while (cap < total) cap <<= 1;
@@ -227,7 +269,7 @@ extern "C" int y2h_nms_sort(const float *boxes, float *probs, int batch, int tot
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)(batch * classes)), dim3(256), lds, S(s),
-                       boxes, probs, total, classes, stride, thresh, cap);
+                       boxes, probs_in, probs, total, classes, stride, thresh, cap);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }

@@ -170,6 +170,7 @@ def lib():
     L.y2h_free.argtypes = [C.c_void_p]
     L.y2h_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.y2h_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.y2h_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.y2h_stream_sync.argtypes = [C.c_void_p]
     L.y2h_set_device.argtypes = [C.c_int]
     _lib = L

@@ -89,12 +89,12 @@ def test_maxpool_matches_oracle_bitwise(dev, oracle, h, w, c, size, stride, pad)
     want = oracle.maxpool(x, n, h, w, c, size, stride, pad).reshape(n, c, oh, ow)
     dx = dev.put(to_nhwc(x))
     dy = dev.empty(n * oh * ow * c * 4)
-    L.y2h_maxpool.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 11 + [C.c_void_p]
+    L.y2h_maxpool.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]
     assert L.y2h_maxpool(dx, c, dy, c, n, h, w, c, size, stride, pad, oh, ow, None) == 0
     assert np.array_equal(to_nchw(dev.get(dy, (n, oh, ow, c))), want)
 
 
-@pytest.mark.parametrize("w,h,c,s", [(2, 2, 4, 2), (2, 2, 8, 2), (4, 2, 4, 2), (38, 38, 64, 2), (6, 4, 9, 3)])
+@pytest.mark.parametrize("w,h,c,s", [(2, 2, 4, 2), (2, 2, 8, 2), (4, 2, 4, 2), (38, 38, 64, 2), (6, 6, 9, 3)])
 @pytest.mark.parametrize("reverse", [0, 1])
 def test_reorg_quirk_matches_oracle_bitwise(dev, oracle, w, h, c, s, reverse):
     L = dev.L
@@ -148,12 +148,8 @@ def test_do_nms_sort_matches_oracle_bitwise(oracle, total, classes, seed, ties):
     for thresh in (0.1, 0.4):
         got = darknet.do_nms_sort(boxes, probs, thresh)
         want = oracle.do_nms_sort(boxes, probs, thresh)
-        if ties:
-            # tied scores: the reference's order among equals is an artefact of its sort; the kept COUNT per
-            # class and every untied decision must still agree
-            assert np.array_equal((got > 0).sum(0), (want > 0).sum(0))
-        else:
-            assert np.array_equal(got, want)
+        # also with tied scores: the kernel reproduces the order the reference's repeated stable sort gives
+        assert np.array_equal(got, want)
     allzero = darknet.do_nms_sort(boxes, np.zeros_like(probs), 0.4)
     assert not allzero.any()
 

@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 
+
+def boxes_close(got, want):
+    """centre x,y within 1e-4 absolute; w,h = exp(t)*anchor can be large, so 1e-4 relative above 1."""
+    scale = np.maximum(1.0, np.abs(want))
+    return bool((np.abs(got - want) < TOL * scale).all())
+
 CASES = ["mini_32_b2", "mini_64_b3", "mini_mfma_64_b2", "tiny_yolo_voc_416_b1", "tiny_yolo_voc_416_b1_kinect",
          "yolo_416_b1", "yolo_608_b1"]
 
@@ -55,7 +61,7 @@ def test_decode_and_nms_match_reference_golden(workdir, name):
     dets, counts = net.detect_resident(thresh, nms)
     for b in range(batch):
         boxes, probs = net.get_region_boxes(1, 1, thresh, batch_item=b)
-        assert np.abs(boxes - g["boxes_%d" % b]).max() < TOL
+        assert boxes_close(boxes, g["boxes_%d" % b])
         pre = dense_from_sparse(g["pre_idx_%d" % b], g["pre_val_%d" % b], total, classes)
         assert np.array_equal(probs > 0, pre > 0), "different set of (box, class) pairs above thresh"
         assert np.abs(probs - pre).max() < TOL
@@ -69,9 +75,10 @@ def test_decode_and_nms_match_reference_golden(workdir, name):
         assert int(counts[b]) == keep.size
         d = dets[b]
         assert np.array_equal(d["obj_id"], gpost[keep].argmax(axis=1))
-        assert np.abs(d["prob"] - gpost[keep].max(axis=1)).max() < TOL
-        got = np.stack([d["x"], d["y"], d["w"], d["h"]], 1)
-        assert np.abs(got - g["boxes_%d" % b][keep]).max() < TOL
+        if keep.size:
+            assert np.abs(d["prob"] - gpost[keep].max(axis=1)).max() < TOL
+            got = np.stack([d["x"], d["y"], d["w"], d["h"]], 1)
+            assert boxes_close(got, g["boxes_%d" % b][keep])
     net.free()
 
 
@@ -169,7 +176,7 @@ def test_yolo9000_tree_head(workdir, name):
     l = net.last
     total, classes = l.w * l.h * l.n, l.classes
     boxes, probs = net.get_region_boxes(1, 1, thresh, use_map=use_map)
-    assert np.abs(boxes - g["boxes_0"]).max() < TOL
+    assert boxes_close(boxes, g["boxes_0"])
     pre = dense_from_sparse(g["pre_idx_0"], g["pre_val_0"], total, classes)
     assert np.array_equal(probs > 0, pre > 0)
     assert np.abs(probs - pre).max() < TOL
