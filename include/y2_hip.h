@@ -77,6 +77,9 @@ int         y2h_event_elapsed_ms(y2h_event start, y2h_event stop, float *ms);   
 /* [n][c][h][w] -> [n][h][w][ld] (channels 0..c-1 of each pixel row) and back */
 int y2h_nchw_to_nhwc(const float *src, float *dst, int n, int c, int h, int w, int ld, y2h_stream s);
 int y2h_nhwc_to_nchw(const float *src, int ld, float *dst, int n, int c, int h, int w, y2h_stream s);
+/* [n][c][h][w] -> interior of [n][h+2][w+2][ld]; the one-pixel border is not written
+ * (the caller zeroes the buffer once) */
+int y2h_nchw_to_nhwc_halo(const float *src, float *dst, int n, int c, int h, int w, int ld, y2h_stream s);
 /* copy `c` channels of `npix` pixels between two NHWC buffers ([route] fallback) */
 int y2h_copy_channels(const float *src, int ld_src, float *dst, int ld_dst, int c, long npix, y2h_stream s);
 
@@ -84,6 +87,8 @@ int y2h_copy_channels(const float *src, int ld_src, float *dst, int ld_dst, int 
 typedef struct y2h_conv {
     int batch, h, w, c;          /* input  NHWC dims                                   */
     int ldx;                     /* input  channel stride (floats)                     */
+    int x_halo;                  /* 0, or 1: x is [batch][h+2][w+2][ldx] with a zero border
+                                    (layout of y2h_nchw_to_nhwc_halo; first-layer kernel only) */
     int n;                       /* filters (output channels)                          */
     int size, stride, pad;       /* square kernel                                      */
     int out_h, out_w;
@@ -102,6 +107,9 @@ typedef struct y2h_conv {
 
 /* which kernel y2h_conv_forward would pick: 1 = MFMA implicit GEMM, 0 = direct VALU */
 int y2h_conv_uses_mfma(const y2h_conv *d);
+/* 1 when the shape fits the dedicated first-layer kernel (3 channels, 3x3/1 pad 1, <= 64
+ * filters) provided the input is supplied with a halo (x_halo = 1) */
+int y2h_conv_first_layer_ok(const y2h_conv *d);
 /* strict != 0 forces the direct kernel, which accumulates in the reference's exact
  * order (ci, kh, kw ascending; product and sum rounded separately: gemm.c:74-88)
  * and is therefore bit-identical to the CPU path; needs w_ref. */

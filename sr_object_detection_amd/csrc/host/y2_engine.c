@@ -138,6 +138,7 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     default: c->activation = -1; break;
     }
     c->x = x;
+    c->x_halo = (i == 0) ? e->in_halo : 0;
     c->y = d->out;
     if (e->arena) {
         c->w_packed = (const float *)(e->arena + d->off_w_packed);
@@ -303,8 +304,23 @@ int y2_engine_build(network *net)
     }
     /* io */
     e->in_floats = (size_t)net->batch * net->inputs;
+    e->in_halo = 0;
+    if (!e->strict && net->n > 0 && net->layers[0].type == CONVOLUTIONAL) {
+        /* a 3-channel 3x3 first layer reads its input with a one-pixel zero halo (no tap bounds tests) */
+        const layer *l0 = &net->layers[0];
+        y2h_conv c0;
+        memset(&c0, 0, sizeof c0);
+        c0.batch = l0->batch; c0.h = l0->h; c0.w = l0->w; c0.c = l0->c; c0.ldx = net->c; c0.n = l0->n;
+        c0.size = l0->size; c0.stride = l0->stride; c0.pad = l0->pad; c0.out_h = l0->out_h; c0.out_w = l0->out_w;
+        c0.w_packed = (const float *)(uintptr_t)256;
+        e->in_halo = y2h_conv_first_layer_ok(&c0);
+    }
     HIPCALL(y2h_malloc((void **)&e->d_in_nchw, e->in_floats * sizeof(float)));
-    HIPCALL(y2h_malloc((void **)&e->d_in_nhwc, e->in_floats * sizeof(float)));
+    {
+        size_t nhwc = e->in_halo ? (size_t)net->batch * (net->h + 2) * (net->w + 2) * net->c : e->in_floats;
+        HIPCALL(y2h_malloc((void **)&e->d_in_nhwc, nhwc * sizeof(float)));
+        HIPCALL(y2h_memset(e->d_in_nhwc, 0, nhwc * sizeof(float), e->stream));     /* the halo stays zero */
+    }
     {
         layer *ol = &net->layers[e->out_layer];
         e->out_floats = (size_t)net->batch * ol->outputs;
@@ -416,7 +432,10 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
     if (ensure_built(net) != 0) return -1;
     e = y2_engine_of(net);
     if (net->c <= 0 || net->h <= 0 || net->w <= 0) { y2_fail("network input must be an image (h,w,c > 0)"); return -1; }
-    HIPCALL(y2h_nchw_to_nhwc(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));
+    if (e->in_halo)
+        HIPCALL(y2h_nchw_to_nhwc_halo(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));
+    else
+        HIPCALL(y2h_nchw_to_nhwc(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));
     if (e->timing) HIPCALL(y2h_event_record(e->ev[0], e->stream));
     for (i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];

@@ -37,6 +37,7 @@ typedef struct y2_engine {
     y2h_stream stream;
     int strict;
     int timing;
+    int in_halo;               /* the NHWC copy of the input carries a one-pixel zero border */
     /* plan state */
     int built;
     int built_batch, built_w, built_h, built_strict;

@@ -167,8 +167,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             const unsigned off = (b_off[q] == a.wbytes) ? a.wbytes : b_off[q] + kadd;
             rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
         }
-        c0 += BK;
-        if (c0 == a.Cin) { c0 = 0; ++tap; }
+        // K order: channel chunk outermost, the KS*KS taps innermost.  The nine taps of one
+        // 32-channel chunk touch the same (neighbouring) 128-byte pixel lines, so eight of the
+        // nine A-slice reads hit L1/L2 instead of going back to the Infinity Cache / HBM.
+        if (++tap == KS * KS) { tap = 0; c0 += BK; }
     };
     auto store_slice = [&](int buf) {
         float *As = smem + buf * BUF;
@@ -232,6 +234,104 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                     a.y[(size_t)p * a.ldy + co] = epilogue(acc[i][j][r], a.bn, mean, rinv, scale, bias, a.act);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// First layer (3 input channels, 3x3, stride 1, pad 1, <= 32*NT filters).
+//
+// K = 27 is too short for the LDS-staged kernel and the layer is HBM bound
+// (0.64 GFLOP against 52 MB per 608x608 image), so it gets its own shape:
+// no LDS at all.  The input is kept with a one-pixel zero halo
+// ([batch][H+2][W+2][ldx]), so no tap needs a bounds test.  A wave takes
+// tiles of 32 consecutive output pixels; lane (i, half) loads A[i][k] for
+// k = 2t + half, t = 0..13 (k = 27 is a dummy with a zero weight) with plain
+// dword loads -- 32 neighbouring pixels are 384 contiguous bytes per tap row --
+// holds the 14 matching filter taps of its filter column in registers for the
+// whole kernel, and issues 14 v_mfma_f32_32x32x2_f32 per tile.  The next
+// tile's loads are in flight while the current one is multiplied.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
+{
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long nwaves = (long)gridDim.x * 4;
+    const long ntiles = ((long)a.npix + 31) / 32;
+    const int W2 = a.W + 2, H2 = a.H + 2, HW = a.H * a.W;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+
+    float bw[NT][14];
+    unsigned delta[14];
+#pragma unroll
+    for (int t = 0; t < 14; ++t) {
+        const int k = 2 * t + lh;
+        const int kk = k < 27 ? k : 26;
+        const int tap = kk / 3, ci = kk - tap * 3;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        delta[t] = (unsigned)(((kh * W2 + kw) * a.ldx + ci) * 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = j * 32 + li;
+            bw[j][t] = (co < a.Cout && k < 27) ? a.w[(size_t)co * 27 + k] : 0.f;
+        }
+    }
+    float mean[NT], scale[NT], bias[NT];
+    double rinv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = j * 32 + li;
+        mean[j] = 0.f; scale[j] = 1.f; bias[j] = 0.f; rinv[j] = 1.0;
+        if (co < a.Cout) {
+            bias[j] = a.bias[co];
+            if (a.bn) { mean[j] = a.mean[co]; rinv[j] = a.rinv[co]; scale[j] = a.scale[co]; }
+        }
+    }
+
+    auto load_tile = [&](long tile, float (&av)[14]) {
+        long p = tile * 32 + li;
+        if (p >= a.npix) p = a.npix - 1;
+        const int n = (int)(p / HW);
+        const int rem = (int)(p - (long)n * HW);
+        const int py = rem / a.W, px = rem - py * a.W;
+        const unsigned base = ((unsigned)(n * H2 + py) * (unsigned)W2 + (unsigned)px) * (unsigned)a.ldx * 4u;
+#pragma unroll
+        for (int t = 0; t < 14; ++t)
+            av[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, base + delta[t], 0, 0));
+    };
+    auto compute_tile = [&](long tile, const float (&av)[14]) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 14; ++t)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bw[j][t], acc[j], 0, 0, 0);
+        const long prow = tile * 32 + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long p = prow + (r & 3) + 8 * (r >> 2);
+                if (co < a.Cout && p < a.npix)
+                    a.y[(size_t)p * a.ldy + co] = epilogue(acc[j][r], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+            }
+        }
+    };
+
+    float a0[14], a1[14];
+    long tile = wave;
+    if (tile < ntiles) load_tile(tile, a0);
+    for (; tile < ntiles; tile += 2 * nwaves) {
+        const long t1 = tile + nwaves, t2 = tile + 2 * nwaves;
+        if (t1 < ntiles) load_tile(t1, a1);
+        compute_tile(tile, a0);
+        if (t2 < ntiles) load_tile(t2, a0);
+        if (t1 < ntiles) compute_tile(t1, a1);
     }
 }
 
@@ -328,10 +428,27 @@ static Variant *pick_variant(const y2h_conv *d)
     return nullptr;
 }
 
-extern "C" int y2h_conv_uses_mfma(const y2h_conv *d) { return mfma_ok(d) && pick_variant(d) ? 1 : 0; }
+// first-layer kernel: 3 channels, 3x3/1 pad 1, <= 64 filters, input stored with a 1-pixel zero halo
+static bool first_ok(const y2h_conv *d)
+{
+    if (d->c != 3 || d->size != 3 || d->stride != 1 || d->pad != 1 || d->n > 64) return false;
+    if (d->out_h != d->h || d->out_w != d->w || d->x_halo != 1) return false;
+    const double xbytes = (double)d->batch * (d->h + 2) * (d->w + 2) * d->ldx * 4.0;
+    return xbytes < 4294967000.0 && d->w_packed != nullptr;
+}
+
+extern "C" int y2h_conv_first_layer_ok(const y2h_conv *d)
+{
+    y2h_conv t = *d;
+    t.x_halo = 1;
+    return first_ok(&t) ? 1 : 0;
+}
+
+extern "C" int y2h_conv_uses_mfma(const y2h_conv *d) { return first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d)) ? 1 : 0; }
 
 extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
 {
+    if (!strict && first_ok(d)) return d->n <= 32 ? "conv_first_mfma_f32_c3_n32" : "conv_first_mfma_f32_c3_n64";
     if (!strict && mfma_ok(d)) {
         Variant *v = pick_variant(d);
         if (v) return v->name;
@@ -356,6 +473,19 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     a.bn = d->batch_normalize; a.act = d->activation;
     a.size = d->size; a.stride = d->stride; a.pad = d->pad; a.out_h = d->out_h; a.out_w = d->out_w; a.batch = d->batch;
 
+    if (!strict && first_ok(d)) {
+        a.w = d->w_packed;
+        a.npix = d->batch * d->h * d->w;
+        a.xbytes = (unsigned)((size_t)d->batch * (d->h + 2) * (d->w + 2) * d->ldx * 4);
+        const long ntiles = ((long)a.npix + 31) / 32;
+        long blocks = (ntiles + 3) / 4;
+        if (blocks > 256 * 4) blocks = 256 * 4;      // 4 waves per SIMD, tiles are grid-strided
+        if (d->n <= 32) hipLaunchKernelGGL(conv_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL(conv_first_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+        Y2H_LAUNCH_CHECK();
+        return Y2H_OK;
+    }
+    if (d->x_halo != 0) return Y2H_EINVAL;       // only the first-layer kernel reads a haloed input
     Variant *v = (!strict && mfma_ok(d)) ? pick_variant(d) : nullptr;
     if (v) {
         a.w = d->w_packed;
