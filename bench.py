@@ -70,11 +70,23 @@ def conv_layer_flops(net):
     return out
 
 
+def usable_cores() -> int:
+    """CPU threads this process may really use: the cgroup quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg_b1: str, wts: str, size: int, iters: int, tmp: str):
     """The reference CPU path on this host's cores, batch 1 (the reference's own mode), wall clock."""
     if iters <= 0:
         return None
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     env = dict(os.environ, OMP_NUM_THREADS=str(cores))
     ref_driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     t0 = time.time()

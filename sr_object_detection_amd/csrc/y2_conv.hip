@@ -36,6 +36,7 @@
 //
 // This file is compiled with -ffp-contract=off: no mul+add below may fuse.
 #include "y2_common.hpp"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -386,6 +387,12 @@ struct Variant {
       (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float), WM * WN * 64, {false} }
 
 static Variant g_variants[] = {
+    // 8 waves (2 per SIMD), ONE workgroup per CU: the co-resident partner wave that hides LDS/barrier
+    // stalls comes from the same workgroup, so a CU never ends up with a lone half-speed pair in the tail
+    VAR(192, 256, 32, 3, 2, 4), VAR(192, 256, 32, 1, 2, 4),
+    VAR(256, 128, 32, 3, 4, 2), VAR(256, 128, 32, 1, 4, 2),
+    VAR(256, 64, 32, 3, 8, 1),  VAR(256, 64, 32, 1, 8, 1),
+    // 4 waves, two workgroups per CU
     VAR(128, 128, 32, 3, 2, 2), VAR(128, 128, 32, 1, 2, 2),
     VAR(128, 64, 32, 3, 2, 2),  VAR(128, 64, 32, 1, 2, 2),
     VAR(64, 64, 32, 3, 2, 2),   VAR(64, 64, 32, 1, 2, 2),
@@ -409,23 +416,53 @@ static bool mfma_ok(const y2h_conv *d)
     return d->w_packed != nullptr;
 }
 
+// Tile choice.  The kernels are MFMA bound, so a CU finishes work at one rate however many
+// workgroups share it; what differs between tile shapes is how evenly the grid divides over the
+// 256 CUs.  Estimated time = (largest number of tiles any CU ends up with) x (tile area).  A kernel
+// whose CU holds `bpc` workgroups is refilled bpc at a time once the first wave of workgroups
+// retires (both partners finish together), so its tail is counted in whole groups of bpc -- this is
+// what made 728 tiles of 128x128 on 19x19x1024 layers run at 62 % MFMA utilisation.  Ties go to the
+// larger tile (fewer L2 bytes per flop).  Y2_CONV_TILE=BMxBN forces a shape (for experiments).
 static Variant *pick_variant(const y2h_conv *d)
 {
     const int bk = (d->c % 32 == 0) ? 32 : 16;
     const long npix = (long)d->batch * d->h * d->w;
-    int bn = d->n <= 32 ? 32 : (d->n <= 64 ? 64 : 128);
-    int bm = 128;
-    if (bn == 128) {
-        // small problems: prefer more, smaller blocks so that all 256 CUs get work
-        const long blocks = ((npix + 127) / 128) * ((d->n + 127) / 128);
-        if (blocks < 2 * 256) { bm = 64; bn = 64; }
-    } else if (bn == 64) {
-        const long blocks = ((npix + 127) / 128) * ((d->n + 63) / 64);
-        if (blocks < 2 * 256) bm = 64;
+    const int CUS = 256;
+    int force_bm = 0, force_bn = 0;
+    if (const char *f = getenv("Y2_CONV_TILE")) sscanf(f, "%dx%d", &force_bm, &force_bn);
+    Variant *best = nullptr;
+    double best_cost = 0;
+    for (Variant &v : g_variants) {
+        if (v.bk != bk || v.ks != d->size) continue;
+        if (force_bm && (v.bm != force_bm || v.bn != force_bn)) continue;
+        const long blocks = ((npix + v.bm - 1) / v.bm) * ((d->n + v.bn - 1) / v.bn);
+        int bpc = (int)(160 * 1024 / v.lds);
+        // two waves per SIMD; the 64x64 tile needs <= 64 VGPRs and fits four
+        const int by_waves = (v.bm * v.bn <= 64 * 64 ? 16 : 8) / (v.threads / 64);
+        if (bpc > by_waves) bpc = by_waves;
+        if (bpc < 1) bpc = 1;
+        long per_cu;
+        if (blocks <= (long)CUS * bpc) per_cu = (blocks + CUS - 1) / CUS;
+        else per_cu = (long)bpc * ((blocks + (long)CUS * bpc - 1) / ((long)CUS * bpc));
+        // measured in-tile efficiency relative to the 192x256 tile (yolo.cfg 608x608 b32 sweep,
+        // profiles/r01_tile_sweep.txt): bigger wave tiles re-read less LDS per MFMA; the small
+        // 64x64 tile wins on short-K 1x1 layers, where prologue/epilogue dominate and four
+        // co-resident workgroups overlap them
+        double eff = 0.6;
+        if (v.bm == 192 && v.bn == 256) eff = 1.0;
+        else if (v.bm == 128 && v.bn == 128) eff = 0.96;
+        else if (v.bm == 256 && v.bn == 128) eff = 0.945;
+        else if (v.bm == 64 && v.bn == 64) eff = (d->size == 1) ? 1.0 : 0.90;
+        else if (v.bm == 128 && v.bn == 64) eff = 0.86;
+        else if (v.bm == 256 && v.bn == 64) eff = 0.82;
+        else if (v.bm == 128 && v.bn == 32) eff = (d->size == 1) ? 0.95 : 0.7;
+        const double cost = (double)per_cu * v.bm * v.bn / eff;
+        if (!best || cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && v.bm * v.bn > best->bm * best->bn)) {
+            best = &v;
+            best_cost = cost;
+        }
     }
-    for (Variant &v : g_variants)
-        if (v.bm == bm && v.bn == bn && v.bk == bk && v.ks == d->size) return &v;
-    return nullptr;
+    return best;
 }
 
 // first-layer kernel: 3 channels, 3x3/1 pad 1, <= 64 filters, input stored with a 1-pixel zero halo
