@@ -76,7 +76,7 @@ __device__ __forceinline__ float epilogue(float v, bool bn, float mean, double r
 // ---------------------------------------------------------------------------
 // MFMA implicit GEMM
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int BK, int KS, int WM, int WN>
+template <int BM, int BN, int BK, int KS, int WM, int WN, bool PIPE>
 __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 {
     constexpr int NT = WM * WN * 64;
@@ -149,6 +149,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     f32x4 ra[PA], rb[PB];
 
     int tap = 0, c0 = 0;      // position of the NEXT slice to load
+    // In the pipelined loop this is also called once past the last slice (c0 == Cin): those loads
+    // read the neighbouring channels / next tap (or beyond the buffer: zeros) into an LDS buffer
+    // nobody consumes -- cheaper than a branch, which would split the scheduling region.
     auto load_slice = [&]() {
         int delta = 0;        // float offset of the tap relative to the centre pixel
         if (KS == 3) {
@@ -188,28 +191,82 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     store_slice(0);
     __syncthreads();
 
+    // One K-step = BK/8 groups of 4*TM*TN MFMAs.  Software pipeline (PIPE): the operand fragments
+    // of group g+1 are read from LDS while group g multiplies (two register sets), the global
+    // loads of the next slice are issued under group 0 and written to the other LDS buffer
+    // before the last group, so that when the workgroup reaches the barrier only the barrier is
+    // left -- the matrix pipe idles for one LDS read latency per K-step instead of one per group
+    // plus the whole staging tail.  sched_barrier pins the phases against the compiler's scheduler.
+    constexpr int NG = BK / 8;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
-        if (more) load_slice();                      // global loads in flight under the MFMAs
         const float *As = smem + cur * BUF + (wm * (BM / WM) + li) * LS + lh * 4;
         const float *Bs = smem + cur * BUF + BM * LS + (wn * (BN / WN) + li) * LS + lh * 4;
+        if (!PIPE) {
+            if (more) load_slice();                  // global loads in flight under the MFMAs
 #pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
-            f32x4 af[TM], bf[TN];
+            for (int kg = 0; kg < NG; ++kg) {
+                f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4 *)&As[i * 32 * LS + kg * 8];
+                for (int i = 0; i < TM; ++i) af[i] = *(const f32x4 *)&As[i * 32 * LS + kg * 8];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4 *)&Bs[j * 32 * LS + kg * 8];
+                for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4 *)&Bs[j * 32 * LS + kg * 8];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_slice(cur ^ 1);
+        } else {
+            f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = *(const f32x4 *)&As[i * 32 * LS];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = *(const f32x4 *)&Bs[j * 32 * LS];
+#pragma unroll
+            for (int kg = 0; kg < NG; ++kg) {
+                const int c = kg & 1, n = c ^ 1;
+                if (kg + 1 < NG) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[n][i] = *(const f32x4 *)&As[i * 32 * LS + (kg + 1) * 8];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[n][j] = *(const f32x4 *)&Bs[j * 32 * LS + (kg + 1) * 8];
+                }
+                if (kg == 0) load_slice();
+                if (kg == NG - 1) store_slice(cur ^ 1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i][s], bf[c][j][s], acc[i][j], 0, 0, 0);
+                // issue order inside the group: one MFMA first (the pipe is busy from here on), then the
+                // fragment reads of the next group, then the staging work one piece per MFMA
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kg + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                if (kg == 0) {
+#pragma unroll
+                    for (int q = 0; q < PA + PB; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                if (kg == NG - 1) {
+#pragma unroll
+                    for (int q = 0; q < PA + PB; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (more) store_slice(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -383,9 +440,12 @@ struct Variant {
 };
 
 #define VAR(BM, BN, BK, KS, WM, WN)                                                             \
-    { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN>, \
+    { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
       (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float), WM * WN * 64, {false} }
 
+#ifndef Y2_PIPE
+#define Y2_PIPE true
+#endif
 static Variant g_variants[] = {
     // 8 waves (2 per SIMD), ONE workgroup per CU: the co-resident partner wave that hides LDS/barrier
     // stalls comes from the same workgroup, so a CU never ends up with a lone half-speed pair in the tail
