@@ -70,6 +70,23 @@ def conv_layer_flops(net):
     return out
 
 
+def pmc_traffic(kernel: str, workload: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (counters cannot be read
+    live): profiles/r*_pmc_traffic.json, produced by tools/pmc_summary.py from separate --pmc runs of this
+    same command (FETCH_SIZE doubled for gfx950, KB -> bytes).  None when no profile covers the kernel."""
+    if workload != "yolo608_b32":
+        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            k = json.load(open(path))["kernels"].get(kernel)
+            if k:
+                return int(k["hbm_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def usable_cores() -> int:
     """CPU threads this process may really use: the cgroup quota when there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0))
@@ -206,7 +223,7 @@ def main():
         if dom:
             ach = per_kernel_flops[dom] / (per_kernel_ms[dom] * 1e-3) / 1e12
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom, args.workload),
                         launches_per_step=per_kernel_launches[dom] // max(args.steps, 1),
                         avg_launch_ms=round(per_kernel_ms[dom] / per_kernel_launches[dom], 4),
                         avg_launch_gflop=round(per_kernel_flops[dom] / per_kernel_launches[dom] / 1e9, 3))

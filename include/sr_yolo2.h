@@ -228,6 +228,9 @@ typedef struct { float x, y, w, h, prob; int obj_id; } y2_det;
 int y2_prepare(network *net);
 /* Force every convolution through the reference-order VALU kernel (bit-identical to the CPU path). */
 void y2_set_strict(network *net, int strict);
+/* conv -> 2x2/2 maxpool pairs are fused by default (the conv pools in its epilogue and the
+ * full-resolution activation is never stored); 0 turns that off, e.g. to inspect every layer. */
+void y2_set_fusion(network *net, int on);
 /* The packed, kernel-layout weight arena (one allocation; what a multi-GPU launcher broadcasts). */
 int y2_weights_arena(network *net, void **dev_ptr, size_t *bytes);
 /* Declare the arena contents valid although load_weights was not called on this process

@@ -93,6 +93,9 @@ typedef struct y2h_conv {
     int size, stride, pad;       /* square kernel                                      */
     int out_h, out_w;
     int ldy;                     /* output channel stride (floats)                     */
+    int fuse_maxpool2;           /* 1: a 2x2 stride-2 pad-0 maxpool follows the activation inside
+                                    the kernel; y is then [batch][out_h/2][out_w/2][ldy]
+                                    (matrix-core kernels only, out_h and out_w even)   */
     int batch_normalize;         /* 1: (x-mean)*rinv*scale + bias ; 0: x + bias        */
     int activation;              /* Y2H_ACT_*                                          */
     const float  *x;             /* device, NHWC                                       */

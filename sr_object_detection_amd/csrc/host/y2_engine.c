@@ -41,6 +41,7 @@ int y2_engine_create(network *net)
     e->device = net->gpu_index;
     e->weights_dirty = 1;
     e->strict = (st && atoi(st) != 0) ? 1 : 0;
+    e->fusion = getenv("Y2_NO_FUSE") ? 0 : 1;
     e->n_layers = net->n;
     e->out_layer = y2_out_layer(net);
     for (i = 0; i < net->n; ++i) {
@@ -49,6 +50,7 @@ int y2_engine_create(network *net)
         d->index = i;
         d->placed_in = -1;
         d->alias_of = -1;
+        d->fused_into = -1;
         net->layers[i].dev = d;
     }
     net->engine = e;
@@ -67,6 +69,7 @@ static void free_plan(network *net)
         y2h_free(d->d_region); d->d_region = NULL;
         y2h_free(d->d_flat); d->d_flat = NULL;
         d->placed_in = -1; d->alias_of = -1; d->copy_mask = 0;
+        d->fused_pool = 0; d->fused_into = -1;
     }
     y2h_free(e->d_in_nchw); e->d_in_nchw = NULL;
     y2h_free(e->d_in_nhwc); e->d_in_nhwc = NULL;
@@ -139,6 +142,7 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     }
     c->x = x;
     c->x_halo = (i == 0) ? e->in_halo : 0;
+    c->fuse_maxpool2 = d->fused_pool;
     c->y = d->out;
     if (e->arena) {
         c->w_packed = (const float *)(e->arena + d->off_w_packed);
@@ -247,6 +251,25 @@ int y2_engine_build(network *net)
                 d->copy_mask |= 1u << k;
         }
     }
+    /* pass 1b: conv -> 2x2/2 maxpool pairs whose full-resolution activation nobody else reads are fused:
+     * the conv kernel pools in its epilogue and writes straight into the maxpool layer's buffer */
+    if (e->fusion && !e->strict) {
+        for (i = 0; i + 1 < net->n; ++i) {
+            layer *l = &net->layers[i], *m = &net->layers[i + 1];
+            int used = 0, j;
+            if (l->type != CONVOLUTIONAL || m->type != MAXPOOL) continue;
+            if (m->size != 2 || m->stride != 2 || m->pad != 0 || (l->out_h & 1) || (l->out_w & 1)) continue;
+            if (l->stride != 1 || l->pad != l->size / 2 || !(l->size == 1 || l->size == 3)) continue;
+            if (!((l->c % 16 == 0) || (i == 0 && l->c == 3 && l->size == 3 && l->n <= 64))) continue;
+            if (i == e->out_layer || ld_of(l)->placed_in >= 0) continue;
+            for (j = 0; j < net->n; ++j)
+                if (net->layers[j].type == ROUTE)
+                    for (k = 0; k < net->layers[j].n; ++k) if (net->layers[j].input_layers[k] == i) used = 1;
+            if (used) continue;
+            ld_of(l)->fused_pool = 1;
+            ld_of(m)->fused_into = i;
+        }
+    }
     /* pass 2: allocate.  Routes first (their sources point into them). */
     for (i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
@@ -263,6 +286,8 @@ int y2_engine_build(network *net)
         y2_ldev *d = ld_of(l);
         switch (l->type) {
         case CONVOLUTIONAL: case MAXPOOL: case REORG:
+            d->kernel = l->type == MAXPOOL ? "maxpool_nhwc" : (l->type == REORG ? "reorg_nhwc" : "conv");
+            if (d->fused_pool) break;            /* writes into the maxpool layer's buffer (set below) */
             if (d->placed_in >= 0) {
                 layer *r = &net->layers[d->placed_in];
                 y2_ldev *rd = ld_of(r);
@@ -276,7 +301,6 @@ int y2_engine_build(network *net)
                 d->out = d->out_alloc;
                 d->out_ld = l->out_c;
             }
-            d->kernel = l->type == MAXPOOL ? "maxpool_nhwc" : (l->type == REORG ? "reorg_nhwc" : "conv");
             break;
         case ROUTE:
             d->kernel = "route(zero-copy)";
@@ -300,6 +324,14 @@ int y2_engine_build(network *net)
         default:
             y2_fail("layer %d: type %d has no device implementation", i, (int)l->type);
             return -1;
+        }
+    }
+    for (i = 0; i + 1 < net->n; ++i) {
+        y2_ldev *d = ld_of(&net->layers[i]);
+        if (d->fused_pool) {
+            d->out = ld_of(&net->layers[i + 1])->out;
+            d->out_ld = ld_of(&net->layers[i + 1])->out_ld;
+            ld_of(&net->layers[i + 1])->kernel = "(fused into the conv before)";
         }
     }
     /* io */
@@ -376,6 +408,16 @@ int y2_engine_build(network *net)
         conv_desc(net, i, &c, x, ldx);
         c.w_packed = (const float *)(uintptr_t)256;       /* alignment stand-in for the query */
         d->uses_mfma = !e->strict && y2h_conv_uses_mfma(&c);
+        if (d->fused_pool && !d->uses_mfma) {
+            /* the shape test above was optimistic (e.g. misaligned input view): give the conv its own buffer back */
+            y2_ldev *md = ld_of(&net->layers[i + 1]);
+            d->fused_pool = 0; md->fused_into = -1; md->kernel = "maxpool_nhwc";
+            d->out_floats = (size_t)l->batch * l->out_h * l->out_w * l->out_c;
+            HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * sizeof(float)));
+            d->out = d->out_alloc; d->out_ld = l->out_c;
+            conv_desc(net, i, &c, x, ldx);
+            c.w_packed = (const float *)(uintptr_t)256;
+        }
         d->has_w_ref = !d->uses_mfma;
         d->off_w_packed = off; off = align_up(off + wbytes, 256);
         if (d->has_w_ref) { d->off_w_ref = off; off = align_up(off + wbytes, 256); }
@@ -386,6 +428,7 @@ int y2_engine_build(network *net)
             d->off_rinv = off; off = align_up(off + l->n * sizeof(double), 64);
         }
         d->kernel = y2h_conv_variant(&c, e->strict);
+        if (d->fused_pool) { snprintf(d->kname, sizeof d->kname, "%s+maxpool2", d->kernel); d->kernel = d->kname; }
     }
     if (off != e->arena_bytes || !e->arena) {
         if (e->arena) y2h_free(e->arena);
@@ -404,6 +447,7 @@ int y2_engine_build(network *net)
     }
     e->built = 1;
     e->built_batch = net->batch; e->built_w = net->w; e->built_h = net->h; e->built_strict = e->strict;
+    e->built_fusion = e->fusion;
     if (e->weights_dirty && !e->weights_external && upload_weights(net) != 0) return -1;
     return 0;
 }
@@ -413,7 +457,7 @@ static int ensure_built(network *net)
     y2_engine *e = y2_engine_of(net);
     if (!e) { y2_fail("network has no engine (was it built by parse_network_cfg?)"); return -1; }
     if (!e->built || e->built_batch != net->batch || e->built_w != net->w || e->built_h != net->h ||
-        e->built_strict != e->strict) {
+        e->built_strict != e->strict || e->built_fusion != e->fusion) {
         if (y2_engine_build(net) != 0) return -1;
     } else {
         HIPCALL(y2h_set_device(e->device));
@@ -449,6 +493,7 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
             HIPCALL(y2h_conv_forward(&c, e->strict, e->stream));
         } break;
         case MAXPOOL:
+            if (d->fused_into >= 0) break;       /* already produced by the conv before it */
             HIPCALL(y2h_maxpool(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->size, l->stride, l->pad,
                                 l->out_h, l->out_w, e->stream));
             break;
@@ -557,6 +602,12 @@ void y2_set_strict(network *net, int strict)
     if (e) e->strict = strict ? 1 : 0;
 }
 
+void y2_set_fusion(network *net, int on)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (e) e->fusion = on ? 1 : 0;
+}
+
 void y2_set_timing(network *net, int on)
 {
     y2_engine *e = y2_engine_of(net);
@@ -613,6 +664,11 @@ int y2_pull_layer_output(network net, int i, float *dst)
     l = &net.layers[i];
     d = ld_of(l);
     n = (size_t)l->batch * l->outputs;
+    if (d->fused_pool) {
+        y2_fail("layer %d is fused with the maxpool behind it and its full-resolution output is never stored; "
+                "call y2_set_fusion(&net, 0) (or set Y2_NO_FUSE=1) to inspect it", i);
+        return -1;
+    }
     HIPCALL(y2h_set_device(e->device));
     if (l->type == REGION || l->type == AVGPOOL || l->type == SOFTMAX || (l->type == COST && (l->out_h == 0 || l->out_w == 0))) {
         HIPCALL(y2h_memcpy_d2h(dst, d->out, n * sizeof(float), e->stream));

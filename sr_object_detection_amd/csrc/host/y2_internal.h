@@ -23,6 +23,9 @@ typedef struct y2_ldev {
     size_t off_w_packed, off_w_ref, off_bias, off_mean, off_scale, off_rinv;
     int has_w_ref;
     int uses_mfma;
+    int fused_pool;            /* conv: the following 2x2/2 maxpool runs in this conv's epilogue */
+    int fused_into;            /* maxpool: index of the conv that computes it, or -1 */
+    char kname[80];
     /* region */
     float *d_anchors;
     int *d_tree_parent, *d_tree_gsize, *d_tree_goff, *d_map;
@@ -37,6 +40,7 @@ typedef struct y2_engine {
     y2h_stream stream;
     int strict;
     int timing;
+    int fusion, built_fusion;  /* conv+maxpool fusion enabled / state of the current plan */
     int in_halo;               /* the NHWC copy of the input carries a one-pixel zero border */
     /* plan state */
     int built;

@@ -52,6 +52,7 @@ struct ConvK {
     const float *bias;
     int H, W, Cin, ldx, Cout, ldy, K;
     int npix;          // batch * H * W (output pixels == input pixels for the MFMA path)
+    int pool;          // 1: a 2x2 stride-2 maxpool is fused behind the activation (see pool_pixel)
     int bn, act;
     unsigned xbytes, wbytes;
     int tiles_n;
@@ -71,6 +72,21 @@ __device__ __forceinline__ float epilogue(float v, bool bn, float mean, double r
     else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));       // activations.h:35
     else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);                             // activations.h:37
     return v;
+}
+
+// Fused conv + 2x2/2 maxpool (maxpool_layer.c:79-114 with size 2, stride 2, pad 0).
+// The GEMM rows are enumerated in POOL-MAJOR order: row r = 4*q + t is pixel
+// (2*yo + t/2, 2*xo + t%2) of pooling window q = (n, yo, xo).  An MFMA accumulator lane holds
+// rows (reg&3) + 8*(reg>>2) + 4*half, i.e. registers 4g..4g+3 are the four pixels of ONE window,
+// so the pool is a max over four registers of the same lane -- no cross-lane traffic -- and the
+// full-resolution activation is never written.  Values are identical to conv followed by maxpool.
+__device__ __forceinline__ int pool_pixel(int r, int H, int W)
+{
+    const int q = r >> 2, t = r & 3;
+    const int Wp = W >> 1, HWp = (H >> 1) * Wp;
+    const int n = q / HWp, rem = q - n * HWp;
+    const int yo = rem / Wp, xo = rem - yo * Wp;
+    return (n * H + 2 * yo + (t >> 1)) * W + 2 * xo + (t & 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -110,12 +126,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     const int HW = a.H * a.W;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-        const int p = p0 + sr + q * RP;
+        const int r = p0 + sr + q * RP;                       // GEMM row
+        const int p = a.pool ? pool_pixel(r, a.H, a.W) : r;   // linear NHWC pixel it stands for
         const int rem = p % HW;
         const int py = rem / a.W, px = rem - py * a.W;
         a_off[q] = ((unsigned)p * (unsigned)a.ldx + (unsigned)sc * 4u) * 4u;
         unsigned m = 0;
-        if (p < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
+        if (r < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
             if (KS == 1) m = 1u;
             else {
 #pragma unroll
@@ -285,11 +302,25 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int prow = p0 + wm * (BM / WM) + i * 32 + 4 * lh;
+            if (a.pool) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = prow + (r & 3) + 8 * (r >> 2);
-                if (cok && p < a.npix)
-                    a.y[(size_t)p * a.ldy + co] = epilogue(acc[i][j][r], a.bn, mean, rinv, scale, bias, a.act);
+                for (int g = 0; g < 4; ++g) {
+                    const int r0 = prow + 8 * g;              // first of the window's four rows
+                    float m = epilogue(acc[i][j][4 * g], a.bn, mean, rinv, scale, bias, a.act);
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) {
+                        const float v = epilogue(acc[i][j][4 * g + t], a.bn, mean, rinv, scale, bias, a.act);
+                        m = (v > m) ? v : m;
+                    }
+                    if (cok && r0 < a.npix) a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = prow + (r & 3) + 8 * (r >> 2);
+                    if (cok && p < a.npix)
+                        a.y[(size_t)p * a.ldy + co] = epilogue(acc[i][j][r], a.bn, mean, rinv, scale, bias, a.act);
+                }
             }
         }
     }
@@ -349,6 +380,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
     auto load_tile = [&](long tile, float (&av)[14]) {
         long p = tile * 32 + li;
         if (p >= a.npix) p = a.npix - 1;
+        if (a.pool) p = pool_pixel((int)p, a.H, a.W);
         const int n = (int)(p / HW);
         const int rem = (int)(p - (long)n * HW);
         const int py = rem / a.W, px = rem - py * a.W;
@@ -372,6 +404,20 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int co = j * 32 + li;
+            if (a.pool) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const long r0 = prow + 8 * g;
+                    float m = epilogue(acc[j][4 * g], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) {
+                        const float v = epilogue(acc[j][4 * g + t], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+                        m = (v > m) ? v : m;
+                    }
+                    if (co < a.Cout && r0 < a.npix) a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long p = prow + (r & 3) + 8 * (r >> 2);
@@ -570,6 +616,12 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     a.bn = d->batch_normalize; a.act = d->activation;
     a.size = d->size; a.stride = d->stride; a.pad = d->pad; a.out_h = d->out_h; a.out_w = d->out_w; a.batch = d->batch;
 
+    if (d->fuse_maxpool2) {
+        // only the matrix-core kernels pool in their epilogue, and 2x2/2 windows need even dims
+        if (strict || (d->h & 1) || (d->w & 1) || !(first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d))))
+            return Y2H_EINVAL;
+        a.pool = 1;
+    }
     if (!strict && first_ok(d)) {
         a.w = d->w_packed;
         a.npix = d->batch * d->h * d->w;

@@ -106,7 +106,13 @@ def test_every_layer_against_oracle(oracle, workdir, name, size, batch):
     cfg, wts, x = materialize(workdir, name, size, batch, 77)
     net = darknet.Network.parse_network_cfg(cfg)
     net.load_weights(wts)
+    fused = net.network_predict(x)
+    assert any("+maxpool2" in net.layer_kernel(i) for i in range(net.n)), "conv+maxpool fusion did not engage"
+    with pytest.raises(darknet.Y2Error, match="fused"):
+        net.pull_layer_output(0)
+    net.set_fusion(False)              # keep every layer's full-resolution output for the comparison
     out = net.network_predict(x)
+    assert np.array_equal(out, fused), "fused conv+maxpool must give the very same values"
     on = oracle.OracleNet(cfg, wts)
     ref = on.predict(x)
     for i in range(net.n):
