@@ -56,6 +56,7 @@ struct ConvK {
     int bn, act;
     unsigned xbytes, wbytes;
     int tiles_n;
+    int ntiles;        // tiles_m * tiles_n; workgroups walk them with stride gridDim.x
     // direct kernel only
     int size, stride, pad, out_h, out_w, batch;
 };
@@ -112,10 +113,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     const int wm = wv / WN, wn = wv % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int bid = blockIdx.x;
-    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
-    const int p0 = tile_m * BM, n0 = tile_n * BN;
-
+    // Persistent workgroups: block b computes tiles b, b+grid, b+2*grid, ... (filter tile fastest).
+    // The staging side runs one slice AHEAD of the MFMA side, across tile boundaries: while the last
+    // K-step of tile T multiplies, the first slice of tile T+1 is already being fetched, so neither a
+    // per-tile prologue latency nor a second launch wave is exposed.
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
 
@@ -123,7 +124,12 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     const int sc = t % CH, sr = t / CH;
     unsigned a_off[PA];      // byte offset of the pixel's channel 0 (+ this thread's chunk)
     unsigned a_msk[PA];      // validity of the KS*KS taps
+    unsigned b_off[PB];
     const int HW = a.H * a.W;
+    // row metadata of the tile the STAGING side is working on (tiles past the end: everything masked)
+    auto setup_tile = [&](int tile) {
+    const bool live = tile < a.ntiles;
+    const int p0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
         const int r = p0 + sr + q * RP;                       // GEMM row
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         const int py = rem / a.W, px = rem - py * a.W;
         a_off[q] = ((unsigned)p * (unsigned)a.ldx + (unsigned)sc * 4u) * 4u;
         unsigned m = 0;
-        if (r < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
+        if (live && r < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
             if (KS == 1) m = 1u;
             else {
 #pragma unroll
@@ -146,29 +152,31 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         }
         a_msk[q] = m;
     }
-    unsigned b_off[PB];
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
         const unsigned co = (unsigned)(n0 + sr + q * RP);
         // rows past Cout (or past the tile) land beyond wbytes and read as zero
-        b_off[q] = (co < (unsigned)a.Cout && sr + q * RP < BN) ? (co * (unsigned)a.K + (unsigned)sc * 4u) * 4u : a.wbytes;
+        b_off[q] = (live && co < (unsigned)a.Cout && sr + q * RP < BN) ? (co * (unsigned)a.K + (unsigned)sc * 4u) * 4u : a.wbytes;
     }
+    };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int nk = KS * KS * (a.Cin / BK);
     f32x4 ra[PA], rb[PB];
 
     int tap = 0, c0 = 0;      // position of the NEXT slice to load
-    // In the pipelined loop this is also called once past the last slice (c0 == Cin): those loads
-    // read the neighbouring channels / next tap (or beyond the buffer: zeros) into an LDS buffer
-    // nobody consumes -- cheaper than a branch, which would split the scheduling region.
+    // i-th tile of this workgroup (a.ntiles = none): b, b+G, b+2G, ...  (Cutting the tile range into
+    // one contiguous chunk per XCD, so that neighbouring pixel tiles share halo rows in one L2, was
+    // measured slower on every layer: profiles/r01_notes.md.)
+    auto tile_at = [&](int i) -> int {
+        const long tl = (long)blockIdx.x + (long)i * gridDim.x;
+        return tl < a.ntiles ? (int)tl : a.ntiles;
+    };
+    int lti = 0;              // staging side: index of its tile in this workgroup's sequence
+    setup_tile(tile_at(0));
+    // After the last slice of the last tile the staging side keeps running one step into a
+    // "tile" past the end whose rows are all masked: those loads are out-of-range buffer accesses
+    // (zeros, no memory traffic) -- cheaper than a branch, which would split the scheduling region.
     auto load_slice = [&]() {
         int delta = 0;        // float offset of the tap relative to the centre pixel
         if (KS == 3) {
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         // K order: channel chunk outermost, the KS*KS taps innermost.  The nine taps of one
         // 32-channel chunk touch the same (neighbouring) 128-byte pixel lines, so eight of the
         // nine A-slice reads hit L1/L2 instead of going back to the Infinity Cache / HBM.
-        if (++tap == KS * KS) { tap = 0; c0 += BK; }
+        if (++tap == KS * KS) { tap = 0; c0 += BK; }     // the hop to the next tile is done by the K loop
     };
     auto store_slice = [&](int buf) {
         float *As = smem + buf * BUF;
@@ -216,12 +224,28 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // plus the whole staging tail.  sched_barrier pins the phases against the compiler's scheduler.
     constexpr int NG = BK / 8;
     int cur = 0;
+    for (int cti = 0;; ++cti) {
+    const int ct = tile_at(cti);
+    if (ct >= a.ntiles) break;
+    const int p0 = (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
+        if (kt == nk - 1) {
+            // the slice fetched during this (last) K-step is the first one of the block's next tile;
+            // switching here, outside the K-step body, keeps that body a single scheduling region
+            setup_tile(tile_at(++lti));
+            tap = 0;
+            c0 = 0;
+        }
         const float *As = smem + cur * BUF + (wm * (BM / WM) + li) * LS + lh * 4;
         const float *Bs = smem + cur * BUF + BM * LS + (wn * (BN / WN) + li) * LS + lh * 4;
         if (!PIPE) {
-            if (more) load_slice();                  // global loads in flight under the MFMAs
+            load_slice();                            // global loads in flight under the MFMAs
 #pragma unroll
             for (int kg = 0; kg < NG; ++kg) {
                 f32x4 af[TM], bf[TN];
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
             }
-            if (more) store_slice(cur ^ 1);
+            store_slice(cur ^ 1);
         } else {
             f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
@@ -324,6 +348,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             }
         }
     }
+    }   // tile loop
 }
 
 // ---------------------------------------------------------------------------
@@ -529,6 +554,15 @@ static bool mfma_ok(const y2h_conv *d)
 // retires (both partners finish together), so its tail is counted in whole groups of bpc -- this is
 // what made 728 tiles of 128x128 on 19x19x1024 layers run at 62 % MFMA utilisation.  Ties go to the
 // larger tile (fewer L2 bytes per flop).  Y2_CONV_TILE=BMxBN forces a shape (for experiments).
+static int variant_bpc(const Variant &v)               // workgroups co-resident on one CU
+{
+    int bpc = (int)(160 * 1024 / v.lds);
+    // two waves per SIMD; the 64x64 tile needs <= 64 VGPRs and fits four
+    const int by_waves = (v.bm * v.bn <= 64 * 64 ? 16 : 8) / (v.threads / 64);
+    if (bpc > by_waves) bpc = by_waves;
+    return bpc < 1 ? 1 : bpc;
+}
+
 static Variant *pick_variant(const y2h_conv *d)
 {
     const int bk = (d->c % 32 == 0) ? 32 : 16;
@@ -542,11 +576,7 @@ static Variant *pick_variant(const y2h_conv *d)
         if (v.bk != bk || v.ks != d->size) continue;
         if (force_bm && (v.bm != force_bm || v.bn != force_bn)) continue;
         const long blocks = ((npix + v.bm - 1) / v.bm) * ((d->n + v.bn - 1) / v.bn);
-        int bpc = (int)(160 * 1024 / v.lds);
-        // two waves per SIMD; the 64x64 tile needs <= 64 VGPRs and fits four
-        const int by_waves = (v.bm * v.bn <= 64 * 64 ? 16 : 8) / (v.threads / 64);
-        if (bpc > by_waves) bpc = by_waves;
-        if (bpc < 1) bpc = 1;
+        const int bpc = variant_bpc(v);
         long per_cu;
         if (blocks <= (long)CUS * bpc) per_cu = (blocks + CUS - 1) / CUS;
         else per_cu = (long)bpc * ((blocks + (long)CUS * bpc - 1) / ((long)CUS * bpc));
@@ -649,7 +679,10 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
             Y2H_CHECK(hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
             if (dev >= 0 && dev < 16) v->attr_set[dev] = true;
         }
-        hipLaunchKernelGGL(v->fn, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(v->threads), v->lds, S(s), a);
+        a.ntiles = (int)(tiles_m * a.tiles_n);
+        long grid = 256L * variant_bpc(*v);          // persistent: at most what is co-resident
+        if (grid > a.ntiles) grid = a.ntiles;
+        hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
         Y2H_LAUNCH_CHECK();
         return Y2H_OK;
     }
