@@ -106,10 +106,15 @@ typedef struct y2h_conv {
     const float  *scale;         /* device [n]  scales              (BN only)          */
     const float  *bias;          /* device [n]                                         */
     float        *y;             /* device, NHWC (already offset to the first channel) */
+    float        *ws;            /* device scratch for split-K partial sums, or 0      */
+    size_t        ws_bytes;      /* size of ws; see y2h_conv_workspace_bytes           */
 } y2h_conv;
 
 /* which kernel y2h_conv_forward would pick: 1 = MFMA implicit GEMM, 0 = direct VALU */
 int y2h_conv_uses_mfma(const y2h_conv *d);
+/* bytes of split-K scratch y2h_conv_forward needs for this descriptor (0 = none): small grids
+ * (13x13 maps at small batch, batch-1 inference) are cut along K so that all 256 CUs get work */
+size_t y2h_conv_workspace_bytes(const y2h_conv *d);
 /* 1 when the shape fits the dedicated first-layer kernel (3 channels, 3x3/1 pad 1, <= 64
  * filters) provided the input is supplied with a halo (x_halo = 1) */
 int y2h_conv_first_layer_ok(const y2h_conv *d);

@@ -74,6 +74,7 @@ static void free_plan(network *net)
     y2h_free(e->d_in_nchw); e->d_in_nchw = NULL;
     y2h_free(e->d_in_nhwc); e->d_in_nhwc = NULL;
     y2h_free(e->d_out_nchw); e->d_out_nchw = NULL;
+    y2h_free(e->d_ws); e->d_ws = NULL; e->ws_bytes = 0;
     y2h_host_free(e->h_out); e->h_out = NULL;
     y2h_free(e->d_boxes); e->d_boxes = NULL;
     y2h_free(e->d_probs); e->d_probs = NULL;
@@ -143,6 +144,8 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     c->x = x;
     c->x_halo = (i == 0) ? e->in_halo : 0;
     c->fuse_maxpool2 = d->fused_pool;
+    c->ws = e->d_ws;
+    c->ws_bytes = e->ws_bytes;
     c->y = d->out;
     if (e->arena) {
         c->w_packed = (const float *)(e->arena + d->off_w_packed);
@@ -429,6 +432,21 @@ int y2_engine_build(network *net)
         }
         d->kernel = y2h_conv_variant(&c, e->strict);
         if (d->fused_pool) { snprintf(d->kname, sizeof d->kname, "%s+maxpool2", d->kernel); d->kernel = d->kname; }
+    }
+    {   /* split-K scratch: the largest request of any conv layer */
+        size_t need = 0;
+        for (i = 0; i < net->n; ++i) {
+            y2h_conv c;
+            const float *x; int ldx;
+            size_t b;
+            if (net->layers[i].type != CONVOLUTIONAL || e->strict) continue;
+            input_view(net, i, &x, &ldx);
+            conv_desc(net, i, &c, x, ldx);
+            c.w_packed = (const float *)(uintptr_t)256;
+            b = y2h_conv_workspace_bytes(&c);
+            if (b > need) need = b;
+        }
+        if (need) { HIPCALL(y2h_malloc((void **)&e->d_ws, need)); e->ws_bytes = need; }
     }
     if (off != e->arena_bytes || !e->arena) {
         if (e->arena) y2h_free(e->arena);

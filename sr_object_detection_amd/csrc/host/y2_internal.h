@@ -54,6 +54,8 @@ typedef struct y2_engine {
     float *d_in_nchw, *d_in_nhwc;
     size_t in_floats;
     float *d_out_nchw;         /* staging when the output layer is image-like */
+    float *d_ws;               /* split-K scratch shared by all conv layers */
+    size_t ws_bytes;
     float *h_out;              /* pinned; what network_predict returns */
     size_t out_floats;
     int out_layer;

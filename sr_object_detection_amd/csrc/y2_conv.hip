@@ -56,7 +56,9 @@ struct ConvK {
     int bn, act;
     unsigned xbytes, wbytes;
     int tiles_n;
-    int ntiles;        // tiles_m * tiles_n; workgroups walk them with stride gridDim.x
+    int ntiles;        // tiles_m * tiles_n * ksplit work items; workgroups walk them with stride gridDim.x
+    int ksplit;        // >= 1: number of K ranges each output tile is cut into (split-K)
+    float *ws;         // split-K partial sums [ksplit][npix][Cout]
     // direct kernel only
     int size, stride, pad, out_h, out_w, batch;
 };
@@ -127,8 +129,16 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     unsigned b_off[PB];
     const int HW = a.H * a.W;
     // row metadata of the tile the STAGING side is working on (tiles past the end: everything masked)
-    auto setup_tile = [&](int tile) {
-    const bool live = tile < a.ntiles;
+    // A work item ("virtual tile") v is K-split ks = v % ksplit of output tile v / ksplit: it covers the
+    // slices [ks*nk/ksplit, (ks+1)*nk/ksplit) of the K loop (split-K, for grids too small to fill 256 CUs).
+    const int nk = KS * KS * (a.Cin / BK);
+    int tap = 0, c0 = 0;      // position of the NEXT slice to load
+    auto setup_tile = [&](int vtile) {
+    const bool live = vtile < a.ntiles;
+    const int tile = vtile / a.ksplit;
+    const int kb = ((vtile - tile * a.ksplit) * nk) / a.ksplit;     // first slice of this work item
+    c0 = (kb / (KS * KS)) * BK;
+    tap = kb % (KS * KS);
     const int p0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
@@ -161,10 +171,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     };
 
     f32x16 acc[TM][TN];
-    const int nk = KS * KS * (a.Cin / BK);
     f32x4 ra[PA], rb[PB];
 
-    int tap = 0, c0 = 0;      // position of the NEXT slice to load
     // i-th tile of this workgroup (a.ntiles = none): b, b+G, b+2G, ...  (Cutting the tile range into
     // one contiguous chunk per XCD, so that neighbouring pixel tiles share halo rows in one L2, was
     // measured slower on every layer: profiles/r01_notes.md.)
@@ -225,8 +233,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     constexpr int NG = BK / 8;
     int cur = 0;
     for (int cti = 0;; ++cti) {
-    const int ct = tile_at(cti);
-    if (ct >= a.ntiles) break;
+    const int vt = tile_at(cti);
+    if (vt >= a.ntiles) break;
+    const int ct = vt / a.ksplit, ks = vt - ct * a.ksplit;
+    const int kb = (ks * nk) / a.ksplit, ke = ((ks + 1) * nk) / a.ksplit;
     const int p0 = (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -234,13 +244,11 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt == nk - 1) {
-            // the slice fetched during this (last) K-step is the first one of the block's next tile;
-            // switching here, outside the K-step body, keeps that body a single scheduling region
+    for (int kt = kb; kt < ke; ++kt) {
+        if (kt == ke - 1) {
+            // the slice fetched during this (last) K-step is the first one of the block's next work
+            // item; switching here, outside the K-step body, keeps that body a single scheduling region
             setup_tile(tile_at(++lti));
-            tap = 0;
-            c0 = 0;
         }
         const float *As = smem + cur * BUF + (wm * (BM / WM) + li) * LS + lh * 4;
         const float *Bs = smem + cur * BUF + BM * LS + (wn * (BN / WN) + li) * LS + lh * 4;
@@ -326,6 +334,16 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int prow = p0 + wm * (BM / WM) + i * 32 + 4 * lh;
+            if (a.ksplit > 1) {
+                // split-K: raw partial sums to the workspace [split][pixel][filter]; splitk_reduce_kernel
+                // adds the splits in a fixed order (reproducible) and applies the epilogue
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = prow + (r & 3) + 8 * (r >> 2);
+                    if (cok && p < a.npix) a.ws[((size_t)ks * a.npix + p) * a.Cout + co] = acc[i][j][r];
+                }
+                continue;
+            }
             if (a.pool) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -349,6 +367,22 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         }
     }
     }   // tile loop
+}
+
+// second pass of a split-K convolution: y[p][co] = epilogue(sum_s ws[s][p][co]), s ascending
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK a)
+{
+    const long total = (long)a.npix * a.Cout;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int co = (int)(idx % a.Cout);
+        const long p = idx / a.Cout;
+        float sum = a.ws[idx];
+        for (int s = 1; s < a.ksplit; ++s) sum += a.ws[(size_t)s * total + idx];
+        float mean = 0.f, scale = 1.f;
+        double rinv = 1.0;
+        if (a.bn) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
+        a.y[(size_t)p * a.ldy + co] = epilogue(sum, a.bn, mean, rinv, scale, a.bias[co], a.act);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -563,20 +597,36 @@ static int variant_bpc(const Variant &v)               // workgroups co-resident
     return bpc < 1 ? 1 : bpc;
 }
 
-static Variant *pick_variant(const y2h_conv *d)
+// Split-K: when even the best tile shape leaves most CUs idle (13x13 grids at small batch, batch-1
+// inference), each output tile is cut into `ksplit` K ranges computed by different workgroups; the
+// partial sums go through an fp32 workspace and splitk_reduce_kernel.  Chosen together with the tile.
+static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
 {
     const int bk = (d->c % 32 == 0) ? 32 : 16;
     const long npix = (long)d->batch * d->h * d->w;
+    const int nk = d->size * d->size * (d->c / bk);
     const int CUS = 256;
-    int force_bm = 0, force_bn = 0;
+    int force_bm = 0, force_bn = 0, force_split = 0;
     if (const char *f = getenv("Y2_CONV_TILE")) sscanf(f, "%dx%d", &force_bm, &force_bn);
+    if (const char *f = getenv("Y2_CONV_KSPLIT")) force_split = atoi(f);
     Variant *best = nullptr;
     double best_cost = 0;
+    int best_split = 1;
     for (Variant &v : g_variants) {
         if (v.bk != bk || v.ks != d->size) continue;
         if (force_bm && (v.bm != force_bm || v.bn != force_bn)) continue;
-        const long blocks = ((npix + v.bm - 1) / v.bm) * ((d->n + v.bn - 1) / v.bn);
+        const long tiles = ((npix + v.bm - 1) / v.bm) * ((d->n + v.bn - 1) / v.bn);
         const int bpc = variant_bpc(v);
+        // split only grids that cannot give every CU one workgroup, keep >= 8 slices per range
+        int ksplit = 1;
+        if (!d->fuse_maxpool2 && tiles < CUS && nk >= 16) {
+            ksplit = (int)((long)CUS * bpc / tiles);
+            if (ksplit > nk / 8) ksplit = nk / 8;
+            if (ksplit > 32) ksplit = 32;
+            if (ksplit < 1) ksplit = 1;
+        }
+        if (force_split > 0 && !d->fuse_maxpool2) ksplit = force_split <= nk ? force_split : nk;
+        const long blocks = tiles * ksplit;
         long per_cu;
         if (blocks <= (long)CUS * bpc) per_cu = (blocks + CUS - 1) / CUS;
         else per_cu = (long)bpc * ((blocks + (long)CUS * bpc - 1) / ((long)CUS * bpc));
@@ -592,13 +642,25 @@ static Variant *pick_variant(const y2h_conv *d)
         else if (v.bm == 128 && v.bn == 64) eff = 0.86;
         else if (v.bm == 256 && v.bn == 64) eff = 0.82;
         else if (v.bm == 128 && v.bn == 32) eff = (d->size == 1) ? 0.95 : 0.7;
-        const double cost = (double)per_cu * v.bm * v.bn / eff;
+        // in CU cycles: one K-step of a tile = bm*bn*bk*2 flop at 256 flop/clk; ~5 K-steps of fixed cost
+        // per work item (measured); a split pays the workspace round trip (~4 TB/s) and a launch
+        double cost = (double)per_cu * v.bm * v.bn * v.bk / 128.0 * ((double)nk / ksplit + 5.0) / eff;
+        if (ksplit > 1) cost += (double)npix * d->n * 4.0 * (ksplit + 1) * 5.75e-4 + 5000.0;
         if (!best || cost < best_cost * 0.999 || (cost <= best_cost * 1.001 && v.bm * v.bn > best->bm * best->bn)) {
             best = &v;
             best_cost = cost;
+            best_split = ksplit;
         }
     }
+    if (ksplit_out) *ksplit_out = best_split;
     return best;
+}
+
+extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)
+{
+    int ksplit = 1;
+    if (d->x_halo || !mfma_ok(d) || !pick_variant(d, &ksplit) || ksplit <= 1) return 0;
+    return (size_t)ksplit * d->batch * d->h * d->w * d->n * sizeof(float);
 }
 
 // first-layer kernel: 3 channels, 3x3/1 pad 1, <= 64 filters, input stored with a 1-pixel zero halo
@@ -665,8 +727,14 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         return Y2H_OK;
     }
     if (d->x_halo != 0) return Y2H_EINVAL;       // only the first-layer kernel reads a haloed input
-    Variant *v = (!strict && mfma_ok(d)) ? pick_variant(d) : nullptr;
+    int ksplit = 1;
+    Variant *v = (!strict && mfma_ok(d)) ? pick_variant(d, &ksplit) : nullptr;
     if (v) {
+        a.ksplit = ksplit;
+        if (ksplit > 1) {
+            if (!d->ws || d->ws_bytes < (size_t)ksplit * d->batch * d->h * d->w * d->n * sizeof(float)) return Y2H_EINVAL;
+            a.ws = d->ws;
+        }
         a.w = d->w_packed;
         a.npix = d->batch * d->h * d->w;
         a.xbytes = (unsigned)((size_t)d->batch * d->h * d->w * d->ldx * 4);
@@ -679,11 +747,15 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
             Y2H_CHECK(hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
             if (dev >= 0 && dev < 16) v->attr_set[dev] = true;
         }
-        a.ntiles = (int)(tiles_m * a.tiles_n);
+        a.ntiles = (int)(tiles_m * a.tiles_n) * ksplit;
         long grid = 256L * variant_bpc(*v);          // persistent: at most what is co-resident
         if (grid > a.ntiles) grid = a.ntiles;
         hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
         Y2H_LAUNCH_CHECK();
+        if (ksplit > 1) {
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(y2h_grid((long)a.npix * a.Cout, 256)), dim3(256), 0, S(s), a);
+            Y2H_LAUNCH_CHECK();
+        }
         return Y2H_OK;
     }
     if (!d->w_ref) return Y2H_EINVAL;     // direct kernel needs the reference-layout weights

@@ -217,6 +217,29 @@ def test_mfma_conv_is_exact_on_integer_data(oracle, workdir, filters, ksize, siz
     on.close()
 
 
+@pytest.mark.parametrize("cin,filters,ksize,size,batch,force", [(64, 192, 3, 13, 1, 0), (64, 1024, 3, 13, 2, 0),
+                                                                (64, 128, 3, 19, 1, 3), (64, 425, 1, 13, 1, 2),
+                                                                (48, 160, 3, 26, 1, 5)])
+def test_split_k_conv_is_exact_on_integer_data(oracle, workdir, monkeypatch, cin, filters, ksize, size, batch, force):
+    """Small grids are cut along K (partial sums through an fp32 workspace + reduce kernel).  With integer data
+    every partial sum is exact, so the split must reproduce the oracle bit for bit; `force` pins the number of
+    K ranges (Y2_CONV_KSPLIT) to also cover uneven splits, 0 lets the cost model choose."""
+    if force:
+        monkeypatch.setenv("Y2_CONV_KSPLIT", str(force))
+    spec = [("conv", cin, 3, 0, "linear"), ("conv", filters, ksize, 0, "linear")]
+    cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 7000 + cin + filters + ksize + size + force)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    out = net.network_predict(x)
+    assert net.layer_kernel(1).startswith("conv_mfma_f32"), net.layer_kernel(1)
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    assert np.abs(ref).max() < 2 ** 22
+    assert np.array_equal(out, ref)
+    net.free()
+    on.close()
+
+
 def test_region_kernel_matches_oracle(oracle, workdir):
     cfg, wts, x = materialize(workdir, "mini", 32, 2, 3)
     net = darknet.Network.parse_network_cfg(cfg)
