@@ -44,7 +44,23 @@ WORKLOADS = {
     # configs[1]
     "yolo416_b8": dict(net="yolo", size=416, batch=8),
     "tiny416_b1": dict(net="tiny-yolo-voc", size=416, batch=1),
+    # configs[3] per-GPU share (64 frames over 8 GPUs), synthetic 9418-node tree (cfg/9k.tree is corrupt)
+    "yolo9000_544_b8": dict(net="yolo9000", size=544, batch=8),
+    # configs[4] network in fp32 (the fp16 path is not built yet)
+    "darknet19_448_b32": dict(net="darknet19", size=448, batch=32),
 }
+
+
+def write_cfg(tmp: str, name: str, size: int, batch: int, fname: str = "net.cfg") -> str:
+    """cfg text (+ synthetic tree for yolo9000) into tmp; returns the cfg path."""
+    tree = None
+    if name == "yolo9000":
+        tree = os.path.join(tmp, "syn9k.tree")
+        if not os.path.exists(tree):
+            synth.write_tree(tree, 9418)
+    cfg = os.path.join(tmp, fname)
+    open(cfg, "w").write(zoo.cfg_text(name, size, size, batch, tree_path=tree))
+    return cfg
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 THRESH, NMS = 0.2, 0.4             # Detector defaults (yolo_v2_class.hpp:45,50)
 
@@ -149,8 +165,7 @@ def main():
     wl = WORKLOADS[args.workload]
     name, size, batch = wl["net"], wl["size"], wl["batch"]
     tmp = tempfile.mkdtemp(prefix="y2bench_r%d_" % rank)
-    cfg = os.path.join(tmp, "net.cfg")
-    open(cfg, "w").write(zoo.cfg_text(name, size, size, batch))
+    cfg = write_cfg(tmp, name, size, batch)
     layers = zoo.resolve(name, size)
 
     L = darknet.lib()
@@ -180,7 +195,11 @@ def main():
     d_x = torch.from_numpy(x).cuda()
     torch.cuda.synchronize()
 
+    is_detector = darknet.LAYER_TYPES[net.last.type] == "REGION"
+
     def step():
+        if not is_detector:                 # classifier: forward + host copy of the class scores
+            return net.predict_device(d_x.data_ptr()), np.zeros(1)
         net.forward_device(d_x.data_ptr())
         return net.detect_resident(THRESH, NMS)
 
@@ -228,8 +247,7 @@ def main():
                         avg_launch_ms=round(per_kernel_ms[dom] / per_kernel_launches[dom], 4),
                         avg_launch_gflop=round(per_kernel_flops[dom] / per_kernel_launches[dom] / 1e9, 3))
         conv_ms = sum(per_kernel_ms.values()) / max(args.steps, 1)
-        cfg_b1 = os.path.join(tmp, "net_b1.cfg")
-        open(cfg_b1, "w").write(zoo.cfg_text(name, size, size, 1))
+        cfg_b1 = write_cfg(tmp, name, size, 1, "net_b1.cfg")
         cpu = cpu_baseline(cfg_b1, wts, size, args.cpu_iters, tmp)
         line = {
             "metric": "images/sec YOLOv2 608x608 fp32" if size == 608 else "images/sec YOLOv2 %dx%d fp32" % (size, size),

@@ -153,6 +153,12 @@ typedef struct y2h_decode {
     int classfix;
     const float *anchors;           /* device [2*num]  (l.biases)                      */
     const int   *tree_parent;       /* device [classes] or 0 (softmax_tree)            */
+    const int   *tree_order;        /* device [classes]: node ids sorted by depth, or 0; with
+                                       tree_level_off [levels+1] and tree_levels > 0 the tree is
+                                       walked level by level (valid only when every parent index
+                                       is smaller than its children's: the caller checks)       */
+    const int   *tree_level_off;
+    int          tree_levels;
     const int   *map;               /* device [200] or 0                               */
     float       *pred;              /* device region output [batch][w*h*num][5+classes];
                                        the tree branch updates it in place, as the
@@ -166,9 +172,11 @@ int y2h_region_boxes(const y2h_decode *d, y2h_stream s);
  * probs rows have `stride` floats; only the first `classes` columns take part.
  * `probs_in` holds the scores and is only read (the tie order of the reference's
  * repeated stable sort depends on the original scores of earlier classes);
- * `probs` must be a separate copy of it, in which suppressed scores are zeroed. */
+ * `probs` must be a separate copy of it, in which suppressed scores are zeroed.
+ * `class_counts` is device scratch of batch*classes ints (non-zero scores per image and class: empty
+ * classes are skipped). */
 int y2h_nms_sort(const float *boxes, const float *probs_in, float *probs, int batch, int total, int classes,
-                 int stride, float thresh, y2h_stream s);
+                 int stride, float thresh, int *class_counts, y2h_stream s);
 /* class-agnostic variant, box.c:279-298 */
 int y2h_nms(const float *boxes, float *probs, int batch, int total, int classes, int stride,
             float thresh, y2h_stream s);
@@ -177,7 +185,8 @@ int y2h_nms(const float *boxes, float *probs, int batch, int total, int classes,
  * image.c:662-738): record = {x,y,w,h,prob,class} (6 floats); counts[b] = number found
  * (may exceed max_per_image; only the first max_per_image are stored). */
 int y2h_collect(const float *boxes, const float *probs, int batch, int total, int classes, int stride,
-                float thresh, float *records, int *counts, int max_per_image, y2h_stream s);
+                float thresh, float *records, int *counts, int max_per_image,
+                float *best_scratch /* device, 2*batch*total floats */, y2h_stream s);
 
 /* separable align-corners bilinear resize of a CHW image (image.c:1950-1992) */
 int y2h_resize_chw(const float *src, int c, int ih, int iw, float *tmp, float *dst, int h, int w, y2h_stream s);

@@ -42,6 +42,7 @@ void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *b
     q.img_w = w; q.img_h = h; q.thresh = thresh; q.only_objectness = only_objectness; q.classfix = l.classfix;
     q.anchors = d->d_anchors;
     q.tree_parent = l.softmax_tree ? d->d_tree_parent : NULL;
+    q.tree_order = d->d_tree_order; q.tree_level_off = d->d_tree_loff; q.tree_levels = d->tree_levels;
     if (l.output >= e->h_out && l.output < e->h_out + e->out_floats && (size_t)(l.output - e->h_out) % l.outputs == 0) {
         d_pred = d->d_region + (l.output - e->h_out);           /* batch item (l.output - h_out)/outputs */
     } else {
@@ -77,15 +78,16 @@ void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *b
 }
 
 /* scratch for the array-in/array-out NMS entry points (not thread-safe, like the reference) */
-static struct { float *d_boxes, *d_probs, *d_probs_in; size_t boxes_cap, probs_cap; y2h_stream stream; int device; } g_nms = {0, 0, 0, 0, 0, 0, -1};
+static struct { float *d_boxes, *d_probs, *d_probs_in; int *d_counts; size_t boxes_cap, probs_cap, counts_cap; y2h_stream stream; int device; } g_nms = {0, 0, 0, 0, 0, 0, 0, 0, -1};
 
-static int nms_scratch(size_t nboxes, size_t nprobs)
+static int nms_scratch(size_t nboxes, size_t nprobs, size_t nclasses)
 {
     int dev = 0;
     if (y2h_device_count() <= 0) { y2_fail("do_nms: no HIP device visible and this library has no CPU path"); return -1; }
     HIPCALL_I(y2h_get_device(&dev));
     if (g_nms.device != dev) {
-        g_nms.d_boxes = g_nms.d_probs = g_nms.d_probs_in = NULL; g_nms.boxes_cap = g_nms.probs_cap = 0; g_nms.stream = NULL;   /* per-device scratch */
+        g_nms.d_boxes = g_nms.d_probs = g_nms.d_probs_in = NULL; g_nms.d_counts = NULL;
+        g_nms.boxes_cap = g_nms.probs_cap = g_nms.counts_cap = 0; g_nms.stream = NULL;   /* per-device scratch */
         g_nms.device = dev;
     }
     if (!g_nms.stream) HIPCALL_I(y2h_stream_create(&g_nms.stream));
@@ -96,6 +98,11 @@ static int nms_scratch(size_t nboxes, size_t nprobs)
         HIPCALL_I(y2h_malloc((void **)&g_nms.d_probs_in, nprobs * sizeof(float)));
         g_nms.probs_cap = nprobs;
     }
+    if (nclasses > g_nms.counts_cap) {
+        y2h_free(g_nms.d_counts);
+        HIPCALL_I(y2h_malloc((void **)&g_nms.d_counts, nclasses * sizeof(int)));
+        g_nms.counts_cap = nclasses;
+    }
     return 0;
 }
 
@@ -104,14 +111,14 @@ static void nms_host(box *boxes, float **probs, int total, int classes, float th
     float *flat;
     int i;
     if (total <= 0 || classes <= 0) return;
-    if (nms_scratch((size_t)total * 4, (size_t)total * classes) != 0) return;
+    if (nms_scratch((size_t)total * 4, (size_t)total * classes, (size_t)classes) != 0) return;
     flat = malloc((size_t)total * classes * sizeof(float));
     for (i = 0; i < total; ++i) memcpy(flat + (size_t)i * classes, probs[i], classes * sizeof(float));
     HIPCALL(y2h_memcpy_h2d(g_nms.d_boxes, boxes, (size_t)total * sizeof(box), g_nms.stream));
     HIPCALL(y2h_memcpy_h2d(g_nms.d_probs, flat, (size_t)total * classes * sizeof(float), g_nms.stream));
     if (sorted) {
         HIPCALL(y2h_memcpy_d2d(g_nms.d_probs_in, g_nms.d_probs, (size_t)total * classes * sizeof(float), g_nms.stream));
-        HIPCALL(y2h_nms_sort(g_nms.d_boxes, g_nms.d_probs_in, g_nms.d_probs, 1, total, classes, classes, thresh, g_nms.stream));
+        HIPCALL(y2h_nms_sort(g_nms.d_boxes, g_nms.d_probs_in, g_nms.d_probs, 1, total, classes, classes, thresh, g_nms.d_counts, g_nms.stream));
     }
     else HIPCALL(y2h_nms(g_nms.d_boxes, g_nms.d_probs, 1, total, classes, classes, thresh, g_nms.stream));
     HIPCALL(y2h_memcpy_d2h(flat, g_nms.d_probs, (size_t)total * classes * sizeof(float), g_nms.stream));
@@ -229,16 +236,17 @@ int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_
     q.img_w = img_w; q.img_h = img_h; q.thresh = thresh; q.classfix = l->classfix;
     q.anchors = d->d_anchors;
     q.tree_parent = l->softmax_tree ? d->d_tree_parent : NULL;
+    q.tree_order = d->d_tree_order; q.tree_level_off = d->d_tree_loff; q.tree_levels = d->tree_levels;
     q.pred = d->d_region; q.boxes = e->d_boxes; q.probs = e->d_probs;
     HIPCALL_I(y2h_region_boxes(&q, e->stream));
     final_probs = e->d_probs;
     if (nms > 0) {
         HIPCALL_I(y2h_memcpy_d2d(e->d_probs_nms, e->d_probs, (size_t)net.batch * e->det_total * l->classes * sizeof(float), e->stream));
-        HIPCALL_I(y2h_nms_sort(e->d_boxes, e->d_probs, e->d_probs_nms, net.batch, e->det_total, l->classes, l->classes, nms, e->stream));
+        HIPCALL_I(y2h_nms_sort(e->d_boxes, e->d_probs, e->d_probs_nms, net.batch, e->det_total, l->classes, l->classes, nms, e->d_class_counts, e->stream));
         final_probs = e->d_probs_nms;
     }
     HIPCALL_I(y2h_collect(e->d_boxes, final_probs, net.batch, e->det_total, l->classes, l->classes, thresh,
-                          e->d_records, e->d_counts, e->det_cap, e->stream));
+                          e->d_records, e->d_counts, e->det_cap, e->d_best, e->stream));
     HIPCALL_I(y2h_memcpy_d2h(e->h_counts, e->d_counts, (size_t)net.batch * sizeof(int), e->stream));
     HIPCALL_I(y2h_stream_sync(e->stream));
     keep = 0;

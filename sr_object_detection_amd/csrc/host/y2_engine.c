@@ -81,6 +81,8 @@ static void free_plan(network *net)
     y2h_free(e->d_probs_nms); e->d_probs_nms = NULL;
     y2h_free(e->d_records); e->d_records = NULL;
     y2h_free(e->d_counts); e->d_counts = NULL;
+    y2h_free(e->d_class_counts); e->d_class_counts = NULL;
+    y2h_free(e->d_best); e->d_best = NULL;
     y2h_host_free(e->h_records); e->h_records = NULL;
     y2h_host_free(e->h_counts); e->h_counts = NULL;
     if (net->layers) net->layers[e->out_layer].output = NULL;
@@ -104,6 +106,7 @@ void y2_engine_destroy(network *net)
         y2_ldev *d = ld_of(&net->layers[i]);
         if (!d) continue;
         y2h_free(d->d_anchors); y2h_free(d->d_tree_parent); y2h_free(d->d_tree_gsize); y2h_free(d->d_tree_goff); y2h_free(d->d_map);
+        y2h_free(d->d_tree_order); y2h_free(d->d_tree_loff);
         free(d);
         net->layers[i].dev = NULL;
     }
@@ -372,6 +375,8 @@ int y2_engine_build(network *net)
             HIPCALL(y2h_malloc((void **)&e->d_probs_nms, (size_t)net->batch * e->det_total * ol->classes * sizeof(float)));
             HIPCALL(y2h_malloc((void **)&e->d_records, (size_t)net->batch * e->det_cap * 6 * sizeof(float)));
             HIPCALL(y2h_malloc((void **)&e->d_counts, (size_t)net->batch * sizeof(int)));
+            HIPCALL(y2h_malloc((void **)&e->d_class_counts, (size_t)net->batch * ol->classes * sizeof(int)));
+            HIPCALL(y2h_malloc((void **)&e->d_best, (size_t)2 * net->batch * e->det_total * sizeof(float)));
             HIPCALL(y2h_host_alloc((void **)&e->h_records, (size_t)net->batch * e->det_cap * 6 * sizeof(float)));
             HIPCALL(y2h_host_alloc((void **)&e->h_counts, (size_t)net->batch * sizeof(int)));
         }
@@ -389,6 +394,34 @@ int y2_engine_build(network *net)
                 upload_small((void **)&d->d_tree_goff, t->group_offset, t->groups * sizeof(int), e->stream)) {
                 y2_fail("tree upload: %s", y2h_last_error());
                 return -1;
+            }
+            {   /* depth levels for the level-parallel hierarchy walk; only valid when parents come first */
+                int *depth = calloc(t->n, sizeof(int)), *order = calloc(t->n, sizeof(int)), *loff, j, ok = 1, maxd = 0, lv;
+                for (j = 0; j < t->n && ok; ++j) {
+                    int par = t->parent[j];
+                    if (par >= j) ok = 0;
+                    else depth[j] = par < 0 ? 0 : depth[par] + 1;
+                    if (ok && depth[j] > maxd) maxd = depth[j];
+                }
+                d->tree_levels = 0;
+                if (ok) {
+                    int pos = 0;
+                    loff = calloc(maxd + 2, sizeof(int));
+                    for (lv = 0; lv <= maxd; ++lv) {
+                        loff[lv] = pos;
+                        for (j = 0; j < t->n; ++j) if (depth[j] == lv) order[pos++] = j;
+                    }
+                    loff[maxd + 1] = pos;
+                    if (upload_small((void **)&d->d_tree_order, order, t->n * sizeof(int), e->stream) ||
+                        upload_small((void **)&d->d_tree_loff, loff, (maxd + 2) * sizeof(int), e->stream)) {
+                        free(depth); free(order); free(loff);
+                        y2_fail("tree upload: %s", y2h_last_error());
+                        return -1;
+                    }
+                    d->tree_levels = maxd + 1;
+                    free(loff);
+                }
+                free(depth); free(order);
             }
         }
         if (l->map && upload_small((void **)&d->d_map, l->map, 200 * sizeof(int), e->stream)) { y2_fail("map upload: %s", y2h_last_error()); return -1; }

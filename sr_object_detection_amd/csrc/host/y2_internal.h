@@ -29,6 +29,8 @@ typedef struct y2_ldev {
     /* region */
     float *d_anchors;
     int *d_tree_parent, *d_tree_gsize, *d_tree_goff, *d_map;
+    int *d_tree_order, *d_tree_loff;   /* nodes by depth level (only when parents precede children) */
+    int tree_levels;
     float *d_region;           /* [batch][outputs] flattened region output */
     /* classifier tail */
     float *d_flat;             /* avgpool / softmax output [batch][outputs] */
@@ -62,6 +64,8 @@ typedef struct y2_engine {
     /* decode / nms buffers for the output region layer */
     float *d_boxes, *d_probs, *d_probs_nms, *d_records;
     int *d_counts;
+    int *d_class_counts;       /* [batch][classes] non-zero scores (NMS skips empty classes) */
+    float *d_best;             /* [2][batch][total] best score / class per box */
     float *h_records;
     int *h_counts;
     int det_cap;               /* records per image */

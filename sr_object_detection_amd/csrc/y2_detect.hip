@@ -27,6 +27,7 @@ struct DecodeK {
     float *boxes;
     float *probs;
     long nboxes;       // batch * w * h * num
+    int tree_seq;      // 1: decode_boxes_kernel also walks the tree sequentially (fallback)
 };
 
 __global__ __launch_bounds__(64) void decode_boxes_kernel(DecodeK d)
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(64) void decode_boxes_kernel(DecodeK d)
     float *bo = d.boxes + gi * 4;
     bo[0] = bx; bo[1] = by; bo[2] = bw; bo[3] = bh;
     float *pr = d.probs + gi * d.classes;
-    if (d.parent) {
-        // tree.c:37-44 hierarchy_predictions: parents precede children, in place
+    if (d.parent && d.tree_seq) {
+        // tree.c:37-44 hierarchy_predictions, sequential form (any node order), in place
         float *p = x + 5;
         for (int j = 0; j < d.classes; ++j) {
             const int par = d.parent[j];
@@ -92,6 +93,64 @@ __global__ __launch_bounds__(256) void decode_probs_kernel(DecodeK d)
     }
 }
 
+// Tree head of one box per workgroup (yolo9000: 9418 classes).  hierarchy_predictions (tree.c:37-44)
+// multiplies every node by its parent's FINAL value when parents precede their children in the file
+// (checked on the host; otherwise decode_boxes_kernel's sequential walk is used), so nodes of one
+// depth level are independent: the class row is staged in LDS and walked level by level.  The
+// products are the same fp32 multiplications, hence bit-identical to the sequential loop.  Then, as
+// region_layer.c:351-367: with a map, probs[j] = obj * p[map[j]] thresholded for j < 200; without,
+// only the deepest class whose probability exceeds .5 (the LAST such index) keeps its value and
+// every other class score is zeroed, in the probs row and in the prediction row itself.
+struct TreeK {
+    const int *order;        // node ids sorted by depth
+    const int *level_off;    // [levels + 1] offsets into order
+    int levels;
+};
+
+__global__ __launch_bounds__(256) void decode_tree_kernel(DecodeK d, TreeK tk)
+{
+    extern __shared__ __attribute__((aligned(16))) float row[];      // [classes]
+    __shared__ int s_best;
+    const long gi = blockIdx.x;
+    const int t = threadIdx.x;
+    const int size = d.classes + 5;
+    float *x = d.pred + gi * size;
+    float *p = x + 5;
+    float *pr = d.probs + gi * d.classes;
+    float scale = x[4];
+    if (d.classfix == -1 && scale < .5) scale = 0;
+    for (int j = t; j < d.classes; j += 256) row[j] = p[j];
+    if (t == 0) s_best = -1;
+    __syncthreads();
+    for (int lv = 1; lv < tk.levels; ++lv) {             // level 0 = roots (parent < 0): unchanged
+        const int b = tk.level_off[lv], e = tk.level_off[lv + 1];
+        for (int i = b + t; i < e; i += 256) {
+            const int j = tk.order[i];
+            row[j] *= row[d.parent[j]];
+        }
+        __syncthreads();
+    }
+    if (d.map) {
+        for (int j = t; j < d.classes; j += 256) p[j] = row[j];
+        for (int j = t; j < 200; j += 256) {
+            const float prob = scale * row[d.map[j]];
+            pr[j] = (prob > d.thresh) ? prob : 0;
+        }
+    } else {
+        int best = -1;
+        for (int j = t; j < d.classes; j += 256) if (row[j] > .5) best = j;   // ascending: keeps the last
+        if (best >= 0) atomicMax(&s_best, best);
+        __syncthreads();
+        best = s_best;
+        for (int j = t; j < d.classes; j += 256) {
+            const float v = (j == best) ? row[j] : 0.f;
+            p[j] = v;
+            pr[j] = (scale > d.thresh) ? v : 0;
+        }
+    }
+    if (d.only_objectness && t == 0) { __threadfence_block(); pr[0] = scale; }
+}
+
 extern "C" int y2h_region_boxes(const y2h_decode *q, y2h_stream s)
 {
     if (!q || !q->pred || !q->boxes || !q->probs || !q->anchors) return Y2H_EINVAL;
@@ -103,8 +162,25 @@ extern "C" int y2h_region_boxes(const y2h_decode *q, y2h_stream s)
     d.anchors = q->anchors; d.parent = q->tree_parent; d.map = q->map;
     d.pred = q->pred; d.boxes = q->boxes; d.probs = q->probs;
     d.nboxes = (long)q->batch * q->w * q->h * q->num;
+    const bool level_tree = d.parent && q->tree_order && q->tree_level_off && q->tree_levels > 0 &&
+                            (size_t)q->classes * sizeof(float) <= 150 * 1024;
+    d.tree_seq = (d.parent && !level_tree) ? 1 : 0;
     hipLaunchKernelGGL(decode_boxes_kernel, dim3((unsigned)((d.nboxes + 63) / 64)), dim3(64), 0, S(s), d);
     Y2H_LAUNCH_CHECK();
+    if (level_tree) {
+        TreeK tk;
+        tk.order = q->tree_order; tk.level_off = q->tree_level_off; tk.levels = q->tree_levels;
+        const size_t lds = (size_t)q->classes * sizeof(float);
+        static bool attr_set[16] = {false};
+        int dev = 0;
+        Y2H_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+            Y2H_CHECK(hipFuncSetAttribute((const void *)decode_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            if (dev >= 0 && dev < 16) attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(decode_tree_kernel, dim3((unsigned)d.nboxes), dim3(256), lds, S(s), d, tk);
+        Y2H_LAUNCH_CHECK();
+    }
     if (!d.parent) {
         hipLaunchKernelGGL(decode_probs_kernel, dim3(y2h_grid(d.nboxes * d.classes, 256)), dim3(256), 0, S(s), d);
         Y2H_LAUNCH_CHECK();
@@ -165,10 +241,23 @@ __device__ __forceinline__ bool tie_before(const float *pin, int stride, int k, 
     return ia < ib;
 }
 
+// non-zero scores per (image, class): classes with fewer than two candidates have nothing to suppress, and
+// with thousands of classes (yolo9000) almost all of them are empty -- their workgroups leave at once
+__global__ __launch_bounds__(256) void class_count_kernel(const float *__restrict__ probs, int *__restrict__ counts,
+                                                          int total, int classes, int stride, long n)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % classes);
+        const long row = idx / classes;                  // b * total + i
+        if (probs[row * stride + k] != 0) atomicAdd(&counts[(row / total) * classes + k], 1);
+    }
+}
+
 __global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ pin_all,
-                                                       float *__restrict__ pout_all,
+                                                       float *__restrict__ pout_all, const int *__restrict__ class_counts,
                                                        int total, int classes, int stride, float thresh, int cap)
 {
+    if (class_counts[blockIdx.x] < 2) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
     unsigned long long *keys = (unsigned long long *)nms_smem;          // [cap]
     unsigned char *dead = (unsigned char *)(keys + cap);                // [cap]
@@ -253,9 +342,10 @@ __global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__
 }
 
 extern "C" int y2h_nms_sort(const float *boxes, const float *probs_in, float *probs, int batch, int total, int classes,
-                            int stride, float thresh, y2h_stream s)
+                            int stride, float thresh, int *class_counts, y2h_stream s)
 {
-    if (!boxes || !probs || !probs_in || probs == probs_in || batch <= 0 || total <= 0 || classes <= 0 || stride < classes)
+    if (!boxes || !probs || !probs_in || !class_counts || probs == probs_in || batch <= 0 || total <= 0 || classes <= 0 ||
+        stride < classes)
         return Y2H_EINVAL;
     if (total > 16384) return Y2H_EINVAL;            // LDS holds every candidate of one class
     int cap = 1;
@@ -268,8 +358,13 @@ extern "C" int y2h_nms_sort(const float *boxes, const float *probs_in, float *pr
         Y2H_CHECK(hipFuncSetAttribute((const void *)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 9));
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
+    Y2H_CHECK(hipMemsetAsync(class_counts, 0, (size_t)batch * classes * sizeof(int), S(s)));
+    const long nel = (long)batch * total * classes;
+    hipLaunchKernelGGL(class_count_kernel, dim3(y2h_grid(nel, 256, 256 * 32)), dim3(256), 0, S(s),
+                       probs_in, class_counts, total, classes, stride, nel);
+    Y2H_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)(batch * classes)), dim3(256), lds, S(s),
-                       boxes, probs_in, probs, total, classes, stride, thresh, cap);
+                       boxes, probs_in, probs, class_counts, total, classes, stride, thresh, cap);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }
@@ -330,15 +425,42 @@ extern "C" int y2h_nms(const float *boxes, float *probs, int batch, int total, i
 // (yolo_v2_class.cpp:221-238, image.c:662-672).  Ordered compaction by a
 // workgroup-wide prefix sum so the record order equals the reference's loop order.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ boxes, const float *__restrict__ probs,
-                                                      int total, int classes, int stride, float thresh,
+// best class per box (utils.c:533 max_index: the FIRST maximum): one wavefront per box, lanes stride the
+// classes in ascending order, then a butterfly reduction that prefers the larger value and, on equal
+// values, the smaller index
+__global__ __launch_bounds__(256) void best_class_kernel(const float *__restrict__ probs, long nboxes, int classes, int stride,
+                                                         float *__restrict__ best_val, int *__restrict__ best_cls)
+{
+    const long box = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (box >= nboxes) return;
+    const float *p = probs + box * stride;
+    float best = p[0];
+    int cls = 0;
+    bool have = (lane == 0);
+    if (!have && lane < classes) { best = p[lane]; cls = lane; have = true; }
+    for (int k = lane + 64; k < classes; k += 64) {
+        const float v = p[k];
+        if (v > best) { best = v; cls = k; }
+    }
+    if (!have) { best = p[0]; cls = 0; }                 // lanes beyond the class count restate element 0
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oc = __shfl_xor(cls, off);
+        if (ov > best || (ov == best && oc < cls)) { best = ov; cls = oc; }
+    }
+    if (lane == 0) { best_val[box] = best; best_cls[box] = cls; }
+}
+
+__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ boxes,
+                                                      const float *__restrict__ best_val, const int *__restrict__ best_cls,
+                                                      int total, float thresh,
                                                       float *__restrict__ records, int *__restrict__ counts, int max_per)
 {
     __shared__ int s_scan[256];
     __shared__ int s_base;
     const int b = blockIdx.x, t = threadIdx.x;
     const float *bx = boxes + (size_t)b * total * 4;
-    const float *pr = probs + (size_t)b * total * stride;
     float *rec = records + (size_t)b * max_per * 6;
     if (t == 0) s_base = 0;
     __syncthreads();
@@ -348,9 +470,8 @@ __global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ 
         float best = 0;
         int keep = 0;
         if (i < total) {
-            const float *p = pr + (size_t)i * stride;
-            best = p[0];
-            for (int k = 1; k < classes; ++k) if (p[k] > best) { best = p[k]; cls = k; }
+            best = best_val[(size_t)b * total + i];
+            cls = best_cls[(size_t)b * total + i];
             keep = best > thresh;
         }
         s_scan[t] = keep;
@@ -376,12 +497,18 @@ __global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ 
 }
 
 extern "C" int y2h_collect(const float *boxes, const float *probs, int batch, int total, int classes, int stride,
-                           float thresh, float *records, int *counts, int max_per_image, y2h_stream s)
+                           float thresh, float *records, int *counts, int max_per_image, float *best_scratch, y2h_stream s)
 {
-    if (!boxes || !probs || !records || !counts || batch <= 0 || total <= 0 || classes <= 0 || stride < classes ||
-        max_per_image <= 0) return Y2H_EINVAL;
+    if (!boxes || !probs || !records || !counts || !best_scratch || batch <= 0 || total <= 0 || classes <= 0 ||
+        stride < classes || max_per_image <= 0) return Y2H_EINVAL;
+    const long nboxes = (long)batch * total;
+    float *best_val = best_scratch;
+    int *best_cls = (int *)(best_scratch + nboxes);
+    hipLaunchKernelGGL(best_class_kernel, dim3((unsigned)((nboxes * 64 + 255) / 256)), dim3(256), 0, S(s),
+                       probs, nboxes, classes, stride, best_val, best_cls);
+    Y2H_LAUNCH_CHECK();
     hipLaunchKernelGGL(collect_kernel, dim3((unsigned)batch), dim3(256), 0, S(s),
-                       boxes, probs, total, classes, stride, thresh, records, counts, max_per_image);
+                       boxes, best_val, best_cls, total, thresh, records, counts, max_per_image);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }

@@ -182,16 +182,41 @@ __device__ __forceinline__ void softmax_seq(const float *in, int n, float temp, 
     for (int i = 0; i < n; ++i) out[i] /= sum;
 }
 
-__global__ __launch_bounds__(64) void softmax_rows_kernel(const float *x, float *y, long rows, int n, float temp)
+// One workgroup per row.  The maximum (order-independent) and the double-precision exp of every
+// element (the expensive part) are done by all lanes; only the fp32 running sum -- whose order the
+// reference fixes -- is walked by one lane, so the result is still bit-identical to softmax_seq.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *x, float *y, long rows, int n, float temp)
 {
-    const long r = (long)blockIdx.x * 64 + threadIdx.x;
-    if (r < rows) softmax_seq(x + r * n, n, temp, y + r * n);
+    __shared__ float s_red[256];
+    __shared__ float s_val;
+    const float *in = x + (long)blockIdx.x * n;
+    float *out = y + (long)blockIdx.x * n;
+    const int t = threadIdx.x;
+    float largest = -FLT_MAX;
+    for (int i = t; i < n; i += 256) if (in[i] > largest) largest = in[i];
+    s_red[t] = largest;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off && s_red[t + off] > s_red[t]) s_red[t] = s_red[t + off];
+        __syncthreads();
+    }
+    largest = s_red[0];
+    for (int i = t; i < n; i += 256) out[i] = (float)exp((double)(in[i] / temp - largest / temp));
+    __syncthreads();
+    if (t == 0) {
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i) sum += out[i];
+        s_val = sum;
+    }
+    __syncthreads();
+    const float sum = s_val;
+    for (int i = t; i < n; i += 256) out[i] /= sum;
 }
 
 extern "C" int y2h_softmax_rows(const float *x, float *y, long rows, int n, float temp, y2h_stream s)
 {
     if (rows <= 0 || n <= 0) return Y2H_EINVAL;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, S(s), x, y, rows, n, temp);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, S(s), x, y, rows, n, temp);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }

@@ -18,8 +18,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     name, size, batch = wl["net"], wl["size"], wl["batch"]
     tmp = tempfile.mkdtemp()
-    cfg = os.path.join(tmp, "n.cfg")
-    open(cfg, "w").write(zoo.cfg_text(name, size, size, batch))
+    cfg = bench.write_cfg(tmp, name, size, batch, "n.cfg")
     wts = os.path.join(tmp, "n.weights")
     synth.write_weights(wts, zoo.resolve(name, size), 31)
     net = darknet.Network.parse_network_cfg(cfg)
