@@ -60,6 +60,8 @@ int         y2h_malloc(void **ptr, size_t bytes);
 int         y2h_free(void *ptr);
 int         y2h_host_alloc(void **ptr, size_t bytes);           /* pinned host memory */
 int         y2h_host_free(void *ptr);
+int         y2h_host_register(void *ptr, size_t bytes);         /* pin an existing host allocation */
+int         y2h_host_unregister(void *ptr);
 int         y2h_memcpy_h2d(void *dst, const void *src, size_t bytes, y2h_stream s);
 int         y2h_memcpy_d2h(void *dst, const void *src, size_t bytes, y2h_stream s);
 int         y2h_memcpy_d2d(void *dst, const void *src, size_t bytes, y2h_stream s);

@@ -35,6 +35,7 @@ void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *b
     float *d_pred, *d_tmp_pred = NULL, *h_probs;
     int *d_tmp_map = NULL;
     if (l.type != REGION || !d || !d->eng || !d->eng->built) { y2_fail("get_region_boxes: layer is not a prepared region layer"); return; }
+    if (!l.output) { y2_fail("get_region_boxes: l.output is NULL"); return; }
     e = d->eng;
     HIPCALL(y2h_set_device(e->device));
     memset(&q, 0, sizeof q);
@@ -248,10 +249,16 @@ int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_
     HIPCALL_I(y2h_collect(e->d_boxes, final_probs, net.batch, e->det_total, l->classes, l->classes, thresh,
                           e->d_records, e->d_counts, e->det_cap, e->d_best, e->stream));
     HIPCALL_I(y2h_memcpy_d2h(e->h_counts, e->d_counts, (size_t)net.batch * sizeof(int), e->stream));
-    HIPCALL_I(y2h_stream_sync(e->stream));
     keep = 0;
-    for (b = 0; b < net.batch; ++b) if (e->h_counts[b] > keep) keep = e->h_counts[b];
-    if (keep > e->det_cap) keep = e->det_cap;
+    if ((size_t)net.batch * e->det_cap * 6 * sizeof(float) <= ((size_t)8 << 20)) {
+        /* small enough: fetch every record block with the counts, one copy and one sync per batch */
+        HIPCALL_I(y2h_memcpy_d2h(e->h_records, e->d_records, (size_t)net.batch * e->det_cap * 6 * sizeof(float), e->stream));
+        HIPCALL_I(y2h_stream_sync(e->stream));
+    } else {
+        HIPCALL_I(y2h_stream_sync(e->stream));
+        for (b = 0; b < net.batch; ++b) if (e->h_counts[b] > keep) keep = e->h_counts[b];
+        if (keep > e->det_cap) keep = e->det_cap;
+    }
     if (keep > 0) {
         /* one strided copy of the used prefix of every image's record block */
         for (b = 0; b < net.batch; ++b) {

@@ -54,7 +54,31 @@ int y2_engine_create(network *net)
         net->layers[i].dev = d;
     }
     net->engine = e;
+    y2_engine_host_output(net);
     return 0;
+}
+
+/* (Re)allocate the host output buffer for the current batch/size and publish it as l.output of the output
+ * layer.  Done at parse time and on set_batch / resize, not at the first predict: the reference allocates
+ * l.output in make_*_layer, and callers copy `layer l = net.layers[n-1]` long before they predict. */
+void y2_engine_host_output(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    layer *ol;
+    size_t need;
+    if (!e || !net->layers) return;
+    e->out_layer = y2_out_layer(net);
+    ol = &net->layers[e->out_layer];
+    need = (size_t)net->batch * ol->outputs;
+    if (need > e->h_out_cap || !e->h_out) {
+        if (e->h_out_pinned) { y2h_host_unregister(e->h_out); e->h_out_pinned = 0; }
+        free(e->h_out);
+        e->h_out = NULL;
+        if (posix_memalign((void **)&e->h_out, 4096, (need ? need : 1) * sizeof(float)) != 0) e->h_out = NULL;
+        if (e->h_out) memset(e->h_out, 0, (need ? need : 1) * sizeof(float));
+        e->h_out_cap = need;
+    }
+    ol->output = e->h_out;
 }
 
 static void free_plan(network *net)
@@ -75,7 +99,6 @@ static void free_plan(network *net)
     y2h_free(e->d_in_nhwc); e->d_in_nhwc = NULL;
     y2h_free(e->d_out_nchw); e->d_out_nchw = NULL;
     y2h_free(e->d_ws); e->d_ws = NULL; e->ws_bytes = 0;
-    y2h_host_free(e->h_out); e->h_out = NULL;
     y2h_free(e->d_boxes); e->d_boxes = NULL;
     y2h_free(e->d_probs); e->d_probs = NULL;
     y2h_free(e->d_probs_nms); e->d_probs_nms = NULL;
@@ -85,7 +108,6 @@ static void free_plan(network *net)
     y2h_free(e->d_best); e->d_best = NULL;
     y2h_host_free(e->h_records); e->h_records = NULL;
     y2h_host_free(e->h_counts); e->h_counts = NULL;
-    if (net->layers) net->layers[e->out_layer].output = NULL;
     e->built = 0;
 }
 
@@ -111,6 +133,8 @@ void y2_engine_destroy(network *net)
         net->layers[i].dev = NULL;
     }
     y2h_free(e->arena);
+    if (e->h_out_pinned) y2h_host_unregister(e->h_out);
+    free(e->h_out);
     if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
     y2h_stream_destroy(e->stream);
     free(e);
@@ -362,9 +386,10 @@ int y2_engine_build(network *net)
     {
         layer *ol = &net->layers[e->out_layer];
         e->out_floats = (size_t)net->batch * ol->outputs;
-        HIPCALL(y2h_host_alloc((void **)&e->h_out, e->out_floats * sizeof(float)));
+        y2_engine_host_output(net);
+        if (!e->h_out) { y2_fail("out of host memory for the network output"); return -1; }
+        if (!e->h_out_pinned && y2h_host_register(e->h_out, e->h_out_cap * sizeof(float)) == 0) e->h_out_pinned = 1;
         HIPCALL(y2h_malloc((void **)&e->d_out_nchw, e->out_floats * sizeof(float)));
-        ol->output = e->h_out;
         if (ol->type == REGION) {
             e->det_total = ol->w * ol->h * ol->n;
             e->det_classes = ol->classes;
@@ -752,7 +777,7 @@ void set_batch_network(network *net, int b)  /* network.c:308-320 */
     if (b <= 0) { y2_fail("set_batch_network: batch %d", b); return; }
     net->batch = b;
     for (i = 0; i < net->n; ++i) net->layers[i].batch = b;
-    /* buffers are re-planned at the next predict if the batch changed */
+    y2_engine_host_output(net);     /* HBM buffers are re-planned at the next predict if the batch changed */
 }
 
 int resize_network(network *net, int w, int h)   /* network.c:322-388 */
@@ -823,6 +848,7 @@ int resize_network(network *net, int w, int h)   /* network.c:322-388 */
     }
     net->outputs = net->layers[y2_out_layer(net)].outputs;
     y2_engine_invalidate(net);
+    y2_engine_host_output(net);
     return 0;
 }
 

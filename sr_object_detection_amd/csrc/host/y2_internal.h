@@ -58,8 +58,11 @@ typedef struct y2_engine {
     float *d_out_nchw;         /* staging when the output layer is image-like */
     float *d_ws;               /* split-K scratch shared by all conv layers */
     size_t ws_bytes;
-    float *h_out;              /* pinned; what network_predict returns */
+    float *h_out;              /* what network_predict returns; allocated at parse time like the reference's
+                                  l.output (callers copy `layer` structs early), pinned once a GPU is in use */
     size_t out_floats;
+    size_t h_out_cap;          /* floats allocated behind h_out */
+    int h_out_pinned;
     int out_layer;
     /* decode / nms buffers for the output region layer */
     float *d_boxes, *d_probs, *d_probs_nms, *d_records;
@@ -86,6 +89,7 @@ y2_engine *y2_engine_of(const network *net);
 int y2_engine_create(network *net);
 void y2_engine_destroy(network *net);
 void y2_engine_invalidate(network *net);
+void y2_engine_host_output(network *net);
 int y2_engine_build(network *net);
 int y2_engine_forward(network *net, const float *d_input_nchw);
 int y2_engine_fetch_output(network *net);

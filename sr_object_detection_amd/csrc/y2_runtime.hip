@@ -37,6 +37,8 @@ extern "C" int y2h_malloc(void **ptr, size_t bytes) { Y2H_CHECK(hipMalloc(ptr, b
 extern "C" int y2h_free(void *ptr) { if (ptr) Y2H_CHECK(hipFree(ptr)); return Y2H_OK; }
 extern "C" int y2h_host_alloc(void **ptr, size_t bytes) { Y2H_CHECK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault)); return Y2H_OK; }
 extern "C" int y2h_host_free(void *ptr) { if (ptr) Y2H_CHECK(hipHostFree(ptr)); return Y2H_OK; }
+extern "C" int y2h_host_register(void *ptr, size_t bytes) { Y2H_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterDefault)); return Y2H_OK; }
+extern "C" int y2h_host_unregister(void *ptr) { if (ptr) Y2H_CHECK(hipHostUnregister(ptr)); return Y2H_OK; }
 
 extern "C" int y2h_memcpy_h2d(void *dst, const void *src, size_t bytes, y2h_stream s)
 {
