@@ -155,12 +155,20 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # Y2_BENCH_BACKEND=gloo + Y2_BENCH_SHARE_GPU=1 rehearse the N>1 path on a box with ONE GPU (all ranks on
+    # cuda:0, broadcast staged through the host); the real multi-GPU run uses nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("Y2_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if os.environ.get("Y2_BENCH_SHARE_GPU") else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     name, size, batch = wl["net"], wl["size"], wl["batch"]
@@ -169,7 +177,7 @@ def main():
     layers = zoo.resolve(name, size)
 
     L = darknet.lib()
-    net = darknet.Network.parse_network_cfg(cfg, gpu=local_rank)
+    net = darknet.Network.parse_network_cfg(cfg, gpu=device_index)
     wts = os.path.join(tmp, "net.weights")
     if rank == 0:
         synth.write_weights(wts, layers, args.seed)
@@ -178,14 +186,17 @@ def main():
     arena_ptr, arena_bytes = net.weights_arena()
     if world > 1:
         # replicate the packed weights: ONE broadcast of the kernel-layout arena over RCCL/xGMI
-        buf = torch.empty(arena_bytes, dtype=torch.uint8, device="cuda")
+        on_gpu = backend == "nccl"
+        buf = torch.empty(arena_bytes, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+        to_buf = L.y2h_memcpy_d2d if on_gpu else L.y2h_memcpy_d2h
+        from_buf = L.y2h_memcpy_d2d if on_gpu else L.y2h_memcpy_h2d
         if rank == 0:
-            assert L.y2h_memcpy_d2d(buf.data_ptr(), arena_ptr, arena_bytes, None) == 0
+            assert to_buf(buf.data_ptr(), arena_ptr, arena_bytes, None) == 0
             L.y2h_device_sync()
         dist.broadcast(buf, src=0)
         torch.cuda.synchronize()
         if rank != 0:
-            assert L.y2h_memcpy_d2d(arena_ptr, buf.data_ptr(), arena_bytes, None) == 0
+            assert from_buf(arena_ptr, buf.data_ptr(), arena_bytes, None) == 0
             L.y2h_device_sync()
             net.weights_resident()
         del buf
@@ -231,7 +242,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
