@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument("--workload", default="yolo608_b32", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-iters", type=int, default=2, help="timed CPU-baseline forwards (0 disables the leg)")
     ap.add_argument("--seed", type=int, default=31)
+    ap.add_argument("--host-input", action="store_true",
+                    help="frames start in (pageable) host memory: the PCIe-inclusive rate noted in DESIGN.md, never `value`")
     return ap.parse_args()
 
 
@@ -211,6 +213,8 @@ def main():
     def step():
         if not is_detector:                 # classifier: forward + host copy of the class scores
             return net.predict_device(d_x.data_ptr()), np.zeros(1)
+        if args.host_input:
+            return net.detect(x, THRESH, NMS)
         net.forward_device(d_x.data_ptr())
         return net.detect_resident(THRESH, NMS)
 
@@ -266,7 +270,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d batch %d per GPU: forward + region decode + NMS(%.1f) + collect, "
-                                   "inputs resident in HBM" % (name + ".cfg", size, size, batch, NMS),
+                                   "%s" % (name + ".cfg", size, size, batch, NMS,
+                                                   "inputs in host memory (PCIe-inclusive)" if args.host_input
+                                                   else "inputs resident in HBM"),
                        "global_batch": batch * world, "parallelism": "frame-sharded x%d (RCCL weight broadcast)" % world,
                        "gflop_per_image": round(zoo.conv_flops(layers) / 1e9, 3),
                        "conv_ms_per_step": round(conv_ms, 3),

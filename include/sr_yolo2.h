@@ -194,6 +194,25 @@ box float_to_box(float *f);                                                     
 void test_detector_img(char **names, image **alphabet, network net, image im, float thresh,
                        object *RecObects, int *objectNumPerFrame);
 
+/* ---- evaluation writers (detector.c:169-243) and the validate loops over in-memory frames ---- */
+int get_coco_image_id(char *filename);                                                    /* detector.c:169 */
+void print_cocos(FILE *fp, char *image_path, box *boxes, float **probs, int num_boxes, int classes, int w, int h);
+void print_detector_detections(FILE **fps, char *id, box *boxes, float **probs, int total, int classes, int w, int h);
+void print_imagenet_detections(FILE *fp, int id, box *boxes, float **probs, int total, int classes, int w, int h);
+char *basecfg(char *cfgfile);                                                             /* utils.c:121 */
+/* validate_detector (detector.c:245-368) with the image list replaced by `n` network-sized CHW frames in
+ * memory: per frame network_predict -> get_region_boxes(l, orig_w, orig_h, .005, .., 0, map) ->
+ * do_nms_sort(.45) -> the writer `eval` selects: "voc" (default; <prefix>/comp4_det_test_<name>.txt per
+ * class, id = basecfg(path)), "coco" (<prefix>/coco_results.json), "imagenet" (200 classes,
+ * <prefix>/imagenet-detection.txt).  Frames are processed net.batch at a time.  Returns 0 / -1. */
+int y2_validate_detector_frames(network net, float *frames, int n, char **paths, int *orig_w, int *orig_h,
+                                char *eval, char *prefix, char **names, int *map);
+/* validate_detector_recall (detector.c:371-450): thresh .2, objectness-only decode, do_nms(.., 1, .4), IoU .5
+ * against truth[truth_first[f] .. truth_first[f+1]) (relative centre-form boxes); prints the reference's
+ * progress line per frame on stderr and returns the running totals. */
+typedef struct { int total, correct, proposals; float avg_iou; } y2_recall;
+int y2_validate_recall_frames(network net, float *frames, int n, const box *truth, const int *truth_first, y2_recall *res);
+
 /* ---- small helpers the callers use (option_list.h:12-19, data.c:474, utils.c, tree.c, image.c) ---- */
 list *read_data_cfg(char *filename);
 char *option_find(list *l, char *key);
@@ -213,6 +232,8 @@ void mean_arrays(float **a, int n, int els, float *avg);   /* utils.c:420 */
 image make_image(int w, int h, int c);     /* image.c:1436 */
 void free_image(image m);                  /* image.c:2245 */
 image resize_image(image im, int w, int h);/* image.c:1950; runs on the GPU */
+image letterbox_image(image im, int w, int h);                   /* image.c:1624; runs on the GPU */
+void letterbox_image_into(image im, int w, int h, image boxed);  /* image.c:1607; runs on the GPU */
 float get_color(int c, int x, int max);    /* image.c:33 */
 void error(const char *s);                 /* utils.c:195: perror + exit(-1) */
 void file_error(char *s);                  /* utils.c:208: message + exit(0) */
@@ -248,6 +269,15 @@ int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_
 /* Host-input convenience: H2D + forward + y2_detect_resident. */
 int y2_detect(network net, float *input, float thresh, float nms, int img_w, int img_h,
               y2_det *dets, int *counts, int max_per_image);
+/* Camera-frame entry: `batch` 8-bit interleaved frames (h x w x c, row pitch `step` bytes; swap_rb
+ * exchanges channels 0 and 2 = BGR->RGB) are uploaded as bytes, converted to [0,1] planes, resized
+ * (letterbox != 0: letterboxed) to the network input on the device, then forward + y2_detect_resident.
+ * Same result as ipl_to_image + rgbgr_image + resize_image/letterbox_image + the float path
+ * (yolo_v2_class.hpp:94-141, yolo_v2_class.cpp:173-249).  y2_ingest_u8 stops after filling the
+ * network's device input (follow with y2_forward_device(net, NULL)). */
+int y2_ingest_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox);
+int y2_detect_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox,
+                 float thresh, float nms, int img_w, int img_h, y2_det *dets, int *counts, int max_per_image);
 /* Copy layer i's activations to host as NCHW [batch][out_c][out_h][out_w] (or [batch][outputs]). */
 int y2_pull_layer_output(network net, int i, float *dst);
 /* Per-layer device time of the last forward in ms (needs y2_set_timing(net,1)); returns layers written. */

@@ -193,6 +193,20 @@ int y2h_collect(const float *boxes, const float *probs, int batch, int total, in
 /* separable align-corners bilinear resize of a CHW image (image.c:1950-1992) */
 int y2h_resize_chw(const float *src, int c, int ih, int iw, float *tmp, float *dst, int h, int w, y2h_stream s);
 
+/* ---- frame ingest: the steps in front of network_predict, on the device ---- */
+/* `batch` 8-bit interleaved frames (h x w x c, row pitch `step` bytes, `frame_bytes` between frames) ->
+ * float planes: dst[b][k][y][x] = (float)(src[..][k'] / 255.), k' = k with planes 0 and 2 exchanged when
+ * swap_rb (BGR->RGB); only the first `planes` planes are written (a BGRA frame's alpha can be dropped).
+ * yolo_v2_class.hpp:94-113,133-141; image.c:2045-2067,1181 */
+int y2h_u8_to_planes(const unsigned char *src, int batch, int h, int w, int c, long step, long frame_bytes,
+                     int planes, int swap_rb, float *dst, y2h_stream s);
+int y2h_fill(float *dst, long n, float v, y2h_stream s);                                   /* image.c:1601 */
+int y2h_embed_chw(const float *src, int c, int sh, int sw, float *dst, int dh, int dw, int dx, int dy,
+                  y2h_stream s);                                                            /* image.c:1087 */
+void y2h_letterbox_dims(int iw, int ih, int w, int h, int *new_w, int *new_h);             /* image.c:1607-1618 */
+/* letterbox_image (image.c:1624): tmp holds c*ih*new_w + c*new_h*new_w floats */
+int y2h_letterbox_chw(const float *src, int c, int ih, int iw, float *tmp, float *dst, int h, int w, y2h_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,13 @@ public:
     YOLODLL_API int get_net_height() const;
     YOLODLL_API std::vector<bbox_t> tracking(std::vector<bbox_t> cur_bbox_vec, int const frames_story = 6);
 
+    // Extension (no reference counterpart): a raw 8-bit interleaved camera frame (w x h x c, row pitch
+    // `step` bytes, BGR(A) when bgr) goes to the GPU as bytes; conversion to [0,1] RGB planes and the
+    // resize to the network size (hpp:94-141 + cpp:195-200 of the reference, done there on the host)
+    // run on the device.  Boxes are in pixels of the frame, exactly as detect(image_t) returns them.
+    YOLODLL_API std::vector<bbox_t> detect_frame(const unsigned char *data, int w, int h, int c, int step,
+                                                 float thresh = 0.2f, bool bgr = true);
+
 #ifdef OPENCV
     // BGR 8-bit cv::Mat -> resized planar RGB float image -> detect -> boxes scaled back to mat's size
     std::vector<bbox_t> detect(cv::Mat mat, float thresh = 0.2f, bool use_mean = false)
@@ -64,7 +71,7 @@ public:
         for (int k = 0; k < im.c; ++k)
             for (int y = 0; y < im.h; ++y)
                 for (int x = 0; x < im.w; ++x)
-                    planes[((size_t)(im.c - 1 - k) * im.h + y) * im.w + x] = small.ptr<unsigned char>(y)[x * im.c + k] / 255.f;
+                    planes[((size_t)(im.c - 1 - k) * im.h + y) * im.w + x] = (float)(small.ptr<unsigned char>(y)[x * im.c + k] / 255.);
         im.data = planes.data();
         std::vector<bbox_t> out = detect(im, thresh, use_mean);
         const float wk = (float)mat.cols / im.w, hk = (float)mat.rows / im.h;

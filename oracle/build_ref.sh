@@ -23,7 +23,7 @@ FILES="network parser option_list list utils blas gemm im2col col2im activations
 convolutional_layer batchnorm_layer maxpool_layer reorg_layer route_layer region_layer
 softmax_layer avgpool_layer cost_layer box tree layer cuda data connected_layer crop_layer
 detection_layer dropout_layer gru_layer rnn_layer crnn_layer local_layer normalization_layer
-shortcut_layer activation_layer deconvolutional_layer matrix"
+shortcut_layer activation_layer deconvolutional_layer matrix detector"
 CFLAGS="-O2 -w -fPIC -fopenmp -ffp-contract=off -iquote $SRC"
 objs=""
 for f in $FILES; do

@@ -218,6 +218,44 @@ def top_k(a, k):
     return idx
 
 
+def write_detections(kind: str, paths, ident, boxes: np.ndarray, probs: np.ndarray, w: int, h: int) -> None:
+    """detector.c:175-243 writers; kind 'voc' (paths = one file per class, ident = image id string),
+    'imagenet' (paths = [file], ident = int), 'coco' (paths = [file], ident = image path).  Appends."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    total, classes = probs.shape
+    k = {"voc": 0, "imagenet": 1, "coco": 2}[kind]
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    L = lib()
+    L.orc_write_detections.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_int, C.c_int]
+    sid = str(ident).encode()
+    if L.orc_write_detections(k, arr, sid, int(ident) if kind == "imagenet" else 0, _p(boxes), _p(probs), total, classes, w, h):
+        raise RuntimeError("orc_write_detections: cannot open an output file")
+
+
+def u8_to_planes(frame: np.ndarray, planes: int, swap_rb: bool) -> np.ndarray:
+    """frame: [h][w][c] uint8 (C-contiguous) -> [planes][h][w] float32 (yolo_v2_class.hpp:94-141)."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w, c = frame.shape
+    out = np.zeros((planes, h, w), dtype=np.float32)
+    L = lib()
+    L.orc_u8_to_planes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_u8_to_planes(_p(frame), h, w, c, w * c, planes, int(swap_rb), _p(out))
+    return out
+
+
+def letterbox_image(im: np.ndarray, w: int, h: int, into: np.ndarray | None = None) -> np.ndarray:
+    """image.c:1624 (into=None) / :1607 letterbox_image_into (into = the box to embed in)."""
+    im = np.ascontiguousarray(im, dtype=np.float32)
+    c, ih, iw = im.shape
+    out = np.zeros((c, h, w), dtype=np.float32) if into is None else np.ascontiguousarray(into, dtype=np.float32).copy()
+    L = lib()
+    L.orc_letterbox_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_letterbox_image(_p(im), iw, ih, c, w, h, int(into is None), _p(out))
+    return out
+
+
 def resize_image(im: np.ndarray, w: int, h: int) -> np.ndarray:
     """im: [c][ih][iw] float32 -> [c][h][w] (src_yolo2/image.c:1950)."""
     im = np.ascontiguousarray(im, dtype=np.float32)

@@ -219,11 +219,38 @@ static int cmd_prim(int argc, char **argv)
     return 0;
 }
 
+/* evalw <in.bin> <total> <classes> <w> <h> <id> <out_prefix> : the reference's evaluation writers
+ * (detector.c:201 print_detector_detections -> <out_prefix>_c<j>.txt per class, detector.c:222
+ * print_imagenet_detections with id 7 -> <out_prefix>_imagenet.txt); input = boxes[total*4] ++ probs[total*classes] */
+void print_detector_detections(FILE **fps, char *id, box *boxes, float **probs, int total, int classes, int w, int h);
+void print_imagenet_detections(FILE *fp, int id, box *boxes, float **probs, int total, int classes, int w, int h);
+static int cmd_evalw(int argc, char **argv)
+{
+    if (argc < 9) return 2;
+    size_t n = 0;
+    float *x = read_floats(argv[2], &n);
+    int total = atoi(argv[3]), classes = atoi(argv[4]), w = atoi(argv[5]), h = atoi(argv[6]), i;
+    char path[1024];
+    box *boxes = (box *)x;
+    float **probs = calloc(total, sizeof(float *));
+    FILE **fps = calloc(classes, sizeof(FILE *));
+    for (i = 0; i < total; ++i) probs[i] = x + (size_t)total * 4 + (size_t)i * classes;
+    for (i = 0; i < classes; ++i) { snprintf(path, sizeof path, "%s_c%d.txt", argv[8], i); fps[i] = fopen(path, "w"); }
+    print_detector_detections(fps, argv[7], boxes, probs, total, classes, w, h);
+    for (i = 0; i < classes; ++i) fclose(fps[i]);
+    snprintf(path, sizeof path, "%s_imagenet.txt", argv[8]);
+    FILE *fp = fopen(path, "w");
+    print_imagenet_detections(fp, 7, boxes, probs, total, classes, w, h);
+    fclose(fp);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: ref_driver net|time|prim ...\n"); return 2; }
     if (!strcmp(argv[1], "net")) return cmd_net(argc, argv);
     if (!strcmp(argv[1], "time")) return cmd_time(argc, argv);
     if (!strcmp(argv[1], "prim")) return cmd_prim(argc, argv);
+    if (!strcmp(argv[1], "evalw")) return cmd_evalw(argc, argv);
     return 2;
 }

@@ -990,6 +990,81 @@ void orc_resize_image(const float *im, int iw, int ih, int ic, int w, int h, flo
     free(part);
 }
 
+/* yolo_v2_class.hpp:94-113 ipl_to_image (out[k][i][j] = data[i*step + j*c + k] / 255.) followed by
+ * hpp:133-141 rgbgr_image (planes 0 and 2 exchanged); image.c:2045-2067 load_image_stb is the same
+ * conversion without the swap.  Only the first `planes` planes are produced. */
+void orc_u8_to_planes(const unsigned char *data, int h, int w, int c, int step, int planes, int swap_rb, float *out)
+{
+    int i, j, k;
+    for (k = 0; k < planes; ++k) {
+        int sk = k;
+        if (swap_rb && c >= 3) sk = (k == 0) ? 2 : (k == 2 ? 0 : k);
+        for (i = 0; i < h; ++i) for (j = 0; j < w; ++j)
+            out[((size_t)k * h + i) * w + j] = data[(size_t)i * step + (size_t)j * c + sk] / 255.;
+    }
+}
+
+/* image.c:1607-1645 letterbox_image / letterbox_image_into: fill = 1 starts from a .5 box (image.c:1637),
+ * fill = 0 embeds into what `boxed` already holds; embed_image :1087 through set_pixel :2121 */
+void orc_letterbox_image(const float *im, int iw, int ih, int ic, int w, int h, int fill, float *boxed)
+{
+    int new_w = iw, new_h = ih, k, x, y, dx, dy;
+    float *resized;
+    if (((float)w / iw) < ((float)h / ih)) { new_w = w; new_h = (ih * w) / iw; }
+    else { new_h = h; new_w = (iw * h) / ih; }
+    resized = calloc((size_t)new_w * new_h * ic, sizeof(float));
+    orc_resize_image(im, iw, ih, ic, new_w, new_h, resized);
+    if (fill) { size_t i, n = (size_t)w * h * ic; for (i = 0; i < n; ++i) boxed[i] = .5; }
+    dx = (w - new_w) / 2; dy = (h - new_h) / 2;
+    for (k = 0; k < ic; ++k) for (y = 0; y < new_h; ++y) for (x = 0; x < new_w; ++x) {
+        int X = dx + x, Y = dy + y;
+        if (X < 0 || Y < 0 || X >= w || Y >= h) continue;
+        boxed[((size_t)k * h + Y) * w + X] = resized[((size_t)k * new_h + y) * new_w + x];
+    }
+    free(resized);
+}
+
+/* Evaluation writers, detector.c:175-243.  kind 0 = print_detector_detections (one file per class,
+ * `paths` = classes file names, appended), 1 = print_imagenet_detections (paths[0], numeric id),
+ * 2 = print_cocos (paths[0]; image id = digits after the last '_' of `id`, detector.c:169; category ids :23).
+ * boxes [total][4] centre form in pixels, probs [total][classes]. */
+static const int orc_coco_ids[80] = {1,2,3,4,5,6,7,8,9,10,11,13,14,15,16,17,18,19,20,21,22,23,24,25,27,28,31,32,33,34,35,
+    36,37,38,39,40,41,42,43,44,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63,64,65,67,70,72,73,74,75,76,77,78,79,
+    80,81,82,84,85,86,87,88,89,90};
+int orc_write_detections(int kind, const char **paths, const char *id, int numeric_id, const float *boxes,
+                         const float *probs, int total, int classes, int w, int h)
+{
+    int i, j, nf = kind == 0 ? classes : 1;
+    FILE **fps = calloc(nf, sizeof(FILE *));
+    for (j = 0; j < nf; ++j) { fps[j] = fopen(paths[j], "a"); if (!fps[j]) return -1; }
+    if (kind == 2) { const char *p = strrchr(id, '_'); numeric_id = p ? atoi(p + 1) : 0; }
+    for (i = 0; i < total; ++i) {
+        const float *b = boxes + (size_t)i * 4;
+        float xmin = b[0] - b[2] / 2.;
+        float xmax = b[0] + b[2] / 2.;
+        float ymin = b[1] - b[3] / 2.;
+        float ymax = b[1] + b[3] / 2.;
+        if (xmin < 0) xmin = 0;
+        if (ymin < 0) ymin = 0;
+        if (xmax > w) xmax = w;
+        if (ymax > h) ymax = h;
+        for (j = 0; j < classes; ++j) {
+            float p = probs[(size_t)i * classes + j];
+            if (!p) continue;
+            if (kind == 0) fprintf(fps[j], "%s %f %f %f %f %f\n", id, p, xmin, ymin, xmax, ymax);
+            else if (kind == 1) fprintf(fps[0], "%d %d %f %f %f %f %f\n", numeric_id, j + 1, p, xmin, ymin, xmax, ymax);
+            else {
+                float bw = xmax - xmin, bh = ymax - ymin;
+                fprintf(fps[0], "{\"image_id\":%d, \"category_id\":%d, \"bbox\":[%f, %f, %f, %f], \"score\":%f},\n",
+                        numeric_id, orc_coco_ids[j], xmin, ymin, bw, bh, p);
+            }
+        }
+    }
+    for (j = 0; j < nf; ++j) fclose(fps[j]);
+    free(fps);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* accessors for ctypes                                                */
 /* ------------------------------------------------------------------ */

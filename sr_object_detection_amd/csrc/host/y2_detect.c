@@ -294,6 +294,103 @@ int y2_detect(network net, float *input, float thresh, float nms, int img_w, int
     return y2_detect_resident(net, thresh, nms, img_w, img_h, dets, counts, max_per_image);
 }
 
+/* letterbox_image_into / letterbox_image (image.c:1607-1645) on the device: aspect-preserving resize,
+ * embedded centred; letterbox_image fills the box with .5 first, _into keeps what `boxed` holds. */
+static int letterbox_device(image im, int w, int h, image boxed, int fill)
+{
+    float *d_src = NULL, *d_tmp = NULL, *d_dst = NULL;
+    y2h_stream s = NULL;
+    int nw, nh, rc;
+    size_t ns = (size_t)im.w * im.h * im.c, nd = (size_t)w * h * im.c, nt;
+    if (y2h_device_count() <= 0) { y2_fail("letterbox_image: no HIP device visible and this library has no CPU path"); return -1; }
+    if (!im.data || !boxed.data || im.w <= 0 || im.h <= 0 || w <= 0 || h <= 0) { y2_fail("letterbox_image: empty image"); return -1; }
+    y2h_letterbox_dims(im.w, im.h, w, h, &nw, &nh);
+    if (nw <= 0 || nh <= 0) { y2_fail("letterbox_image: degenerate size %d x %d", nw, nh); return -1; }
+    nt = (size_t)im.c * im.h * nw + (size_t)im.c * nh * nw;
+    if (gpu_index >= 0) y2h_set_device(gpu_index);
+    rc = y2h_stream_create(&s) || y2h_malloc((void **)&d_src, ns * 4) || y2h_malloc((void **)&d_tmp, nt * 4) ||
+         y2h_malloc((void **)&d_dst, nd * 4) || y2h_memcpy_h2d(d_src, im.data, ns * 4, s);
+    if (!rc) {
+        if (fill) rc = y2h_letterbox_chw(d_src, im.c, im.h, im.w, d_tmp, d_dst, h, w, s);
+        else {
+            float *d_res = d_tmp + (size_t)im.c * im.h * nw;
+            rc = y2h_memcpy_h2d(d_dst, boxed.data, nd * 4, s) || y2h_resize_chw(d_src, im.c, im.h, im.w, d_tmp, d_res, nh, nw, s) ||
+                 y2h_embed_chw(d_res, im.c, nh, nw, d_dst, h, w, (w - nw) / 2, (h - nh) / 2, s);
+        }
+    }
+    rc = rc || y2h_memcpy_d2h(boxed.data, d_dst, nd * 4, s) || y2h_stream_sync(s);
+    if (rc) y2_fail("letterbox_image: %s", y2h_last_error());
+    y2h_free(d_src); y2h_free(d_tmp); y2h_free(d_dst);
+    y2h_stream_destroy(s);
+    return rc ? -1 : 0;
+}
+
+image letterbox_image(image im, int w, int h)
+{
+    image boxed = make_image(w, h, im.c);
+    letterbox_device(im, w, h, boxed, 1);
+    return boxed;
+}
+
+void letterbox_image_into(image im, int w, int h, image boxed) { letterbox_device(im, w, h, boxed, 0); }
+
+/* Frames as a camera hands them over: `batch` 8-bit interleaved images (h x w x c, BGR/BGRA/RGB, row
+ * pitch `step` bytes) of any size.  One H2D of the bytes (a quarter of the float image), then on the
+ * device: u8 -> [0,1] planes (+ BGR->RGB), resize_image or letterbox_image to the network's input,
+ * forward, decode, NMS, compaction.  Equivalent to the reference's per-frame host sequence
+ * ipl_to_image + rgbgr_image + resize_image + network_predict + get_region_boxes + do_nms_sort
+ * (yolo_v2_class.cpp:173-249 with the hpp:59-76 glue). */
+static int grow(void **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    y2h_free(*p); *p = NULL; *cap = 0;
+    if (y2h_malloc(p, need) != 0) return -1;
+    *cap = need;
+    return 0;
+}
+
+int y2_ingest_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox)
+{
+    y2_engine *e;
+    size_t frame_bytes, nplanes, ntmp = 0;
+    int planes, nw = net.w, nh = net.h;
+    if (!frames || h <= 0 || w <= 0 || c <= 0 || step < w * c) { y2_fail("y2_ingest_u8: bad frame geometry"); return -1; }
+    if (c < net.c) { y2_fail("y2_ingest_u8: frames have %d channels, the network reads %d", c, net.c); return -1; }
+    if (y2_prepare(&net) != 0) return -1;
+    e = y2_engine_of(&net);
+    HIPCALL_I(y2h_set_device(e->device));
+    planes = net.c;                       /* a 4th (alpha) plane is never read by the network (detector.c:567) */
+    frame_bytes = (size_t)step * h;
+    nplanes = (size_t)net.batch * planes * h * w;
+    if (grow((void **)&e->d_u8, &e->u8_cap, frame_bytes * net.batch)) { y2_fail("y2_ingest_u8: %s", y2h_last_error()); return -1; }
+    HIPCALL_I(y2h_memcpy_h2d(e->d_u8, frames, frame_bytes * net.batch, e->stream));
+    if (w == net.w && h == net.h) {
+        HIPCALL_I(y2h_u8_to_planes(e->d_u8, net.batch, h, w, c, step, (long)frame_bytes, planes, swap_rb, e->d_in_nchw, e->stream));
+        return 0;
+    }
+    if (letterbox) y2h_letterbox_dims(w, h, net.w, net.h, &nw, &nh);
+    if (nw <= 0 || nh <= 0) { y2_fail("y2_ingest_u8: degenerate letterbox %d x %d", nw, nh); return -1; }
+    ntmp = (size_t)net.batch * planes * h * nw + (letterbox ? (size_t)net.batch * planes * nh * nw : 0);
+    if (grow((void **)&e->d_planes, &e->planes_cap, nplanes * 4) || grow((void **)&e->d_rtmp, &e->rtmp_cap, ntmp * 4)) {
+        y2_fail("y2_ingest_u8: %s", y2h_last_error()); return -1;
+    }
+    HIPCALL_I(y2h_u8_to_planes(e->d_u8, net.batch, h, w, c, step, (long)frame_bytes, planes, swap_rb, e->d_planes, e->stream));
+    /* planes are independent in resize/embed, so the whole batch goes through as batch*planes planes */
+    if (letterbox) HIPCALL_I(y2h_letterbox_chw(e->d_planes, net.batch * planes, h, w, e->d_rtmp, e->d_in_nchw, net.h, net.w, e->stream));
+    else HIPCALL_I(y2h_resize_chw(e->d_planes, net.batch * planes, h, w, e->d_rtmp, e->d_in_nchw, net.h, net.w, e->stream));
+    return 0;
+}
+
+int y2_detect_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox,
+                 float thresh, float nms, int img_w, int img_h, y2_det *dets, int *counts, int max_per_image)
+{
+    y2_engine *e;
+    if (y2_ingest_u8(net, frames, h, w, c, step, swap_rb, letterbox) != 0) return -1;
+    e = y2_engine_of(&net);
+    if (y2_forward_device(net, e->d_in_nchw) != 0) return -1;
+    return y2_detect_resident(net, thresh, nms, img_w, img_h, dets, counts, max_per_image);
+}
+
 /* detector.c:558-598 test_detector_img: resize -> predict -> get_region_boxes(1,1,thresh) ->
  * do_nms_sort(nms=0.1) -> draw_detections_test, which fills RecObects (image.c:662-738).
  * Reads exactly net.inputs floats of the resized image (planes 0..2; a 4th plane is ignored). */

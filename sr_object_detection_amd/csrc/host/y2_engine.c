@@ -99,6 +99,9 @@ static void free_plan(network *net)
     y2h_free(e->d_in_nhwc); e->d_in_nhwc = NULL;
     y2h_free(e->d_out_nchw); e->d_out_nchw = NULL;
     y2h_free(e->d_ws); e->d_ws = NULL; e->ws_bytes = 0;
+    y2h_free(e->d_u8); e->d_u8 = NULL; e->u8_cap = 0;
+    y2h_free(e->d_planes); e->d_planes = NULL; e->planes_cap = 0;
+    y2h_free(e->d_rtmp); e->d_rtmp = NULL; e->rtmp_cap = 0;
     y2h_free(e->d_boxes); e->d_boxes = NULL;
     y2h_free(e->d_probs); e->d_probs = NULL;
     y2h_free(e->d_probs_nms); e->d_probs_nms = NULL;
@@ -552,6 +555,7 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
     if (ensure_built(net) != 0) return -1;
     e = y2_engine_of(net);
     if (net->c <= 0 || net->h <= 0 || net->w <= 0) { y2_fail("network input must be an image (h,w,c > 0)"); return -1; }
+    if (!d_input_nchw) d_input_nchw = e->d_in_nchw;     /* filled by y2_ingest_u8 */
     if (e->in_halo)
         HIPCALL(y2h_nchw_to_nhwc_halo(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));
     else

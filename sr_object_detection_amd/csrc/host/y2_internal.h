@@ -56,6 +56,9 @@ typedef struct y2_engine {
     float *d_in_nchw, *d_in_nhwc;
     size_t in_floats;
     float *d_out_nchw;         /* staging when the output layer is image-like */
+    unsigned char *d_u8;       /* y2_detect_u8: raw frames, float planes, resize scratch (grow-only) */
+    float *d_planes, *d_rtmp;
+    size_t u8_cap, planes_cap, rtmp_cap;
     float *d_ws;               /* split-K scratch shared by all conv layers */
     size_t ws_bytes;
     float *h_out;              /* what network_predict returns; allocated at parse time like the reference's

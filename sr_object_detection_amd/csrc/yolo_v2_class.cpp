@@ -181,6 +181,24 @@ std::vector<bbox_t> Detector::detect(image_t img, float thresh, bool use_mean)
     return out;
 }
 
+std::vector<bbox_t> Detector::detect_frame(const unsigned char *data, int w, int h, int c, int step, float thresh, bool bgr)
+{
+    DetectorState &st = state_of(detector_gpu_ptr);
+    network &net = st.net;
+    if (!data) throw std::runtime_error("Image is empty");
+    const layer &last = net.layers[net.n - 1];
+    const int total = last.w * last.h * last.n;
+    int count = 0;
+    if (y2_detect_u8(net, data, h, w, c, step, bgr ? 1 : 0, 0, thresh, nms, 1, 1, st.dets.data(), &count, total) != 0)
+        throw std::runtime_error(y2_last_error());
+    std::vector<bbox_t> out;
+    for (int i = 0; i < std::min(count, total); ++i) {
+        const y2_det &d = st.dets[i];
+        out.push_back(to_bbox(d.x, d.y, d.w, d.h, d.prob, d.obj_id, w, h));
+    }
+    return out;
+}
+
 std::vector<bbox_t> Detector::tracking(std::vector<bbox_t> cur, int const frames_story)
 {
     DetectorState &st = state_of(detector_gpu_ptr);

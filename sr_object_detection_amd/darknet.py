@@ -87,6 +87,10 @@ class CNetwork(C.Structure):  # include/sr_yolo2.h struct network
     ]
 
 
+class Recall(C.Structure):   # include/sr_yolo2.h y2_recall
+    _fields_ = [("total", C.c_int), ("correct", C.c_int), ("proposals", C.c_int), ("avg_iou", C.c_float)]
+
+
 class Det(C.Structure):
     _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float), ("prob", C.c_float),
                 ("obj_id", C.c_int)]
@@ -138,6 +142,26 @@ def lib():
     L.resize_image.restype = Image
     L.resize_image.argtypes = [Image, C.c_int, C.c_int]
     L.free_image.argtypes = [Image]
+    L.print_detector_detections.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_void_p, C.POINTER(C.POINTER(C.c_float)),
+                                            C.c_int, C.c_int, C.c_int, C.c_int]
+    L.print_imagenet_detections.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.POINTER(C.c_float)),
+                                            C.c_int, C.c_int, C.c_int, C.c_int]
+    L.print_cocos.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.POINTER(C.c_float)),
+                              C.c_int, C.c_int, C.c_int, C.c_int]
+    L.get_coco_image_id.argtypes = [C.c_char_p]
+    L.basecfg.restype = C.c_void_p
+    L.basecfg.argtypes = [C.c_char_p]
+    L.y2_validate_detector_frames.argtypes = [CNetwork, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p,
+                                              C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_void_p]
+    L.y2_validate_recall_frames.argtypes = [CNetwork, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Recall)]
+    L.letterbox_image.restype = Image
+    L.letterbox_image.argtypes = [Image, C.c_int, C.c_int]
+    L.letterbox_image_into.argtypes = [Image, C.c_int, C.c_int, Image]
+    L.y2_ingest_u8.argtypes = [CNetwork, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.y2_detect_u8.argtypes = [CNetwork, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.y2h_u8_to_planes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]
     L.top_predictions.argtypes = [CNetwork, C.c_int, C.c_void_p]
     L.cuda_set_device.argtypes = [C.c_int]
     L.y2_prepare.argtypes = [C.POINTER(CNetwork)]
@@ -181,6 +205,7 @@ def lib():
 def _check():
     L = lib()
     msg = L.y2_last_error()
+    L.y2_failed_and_clear()          # the error is being raised here: do not let the flag leak into the next call
     return msg.decode() if msg else ""
 
 
@@ -375,6 +400,59 @@ class Network:
             raise Y2Error("y2_detect: " + _check())
         return [dets[b, :min(int(counts[b]), cap)].copy() for b in range(self.net.batch)], counts
 
+    def detect_u8(self, frames: np.ndarray, thresh: float, nms: float, swap_rb: bool = True, letterbox: bool = False,
+                  img_w: int = 1, img_h: int = 1):
+        """frames: [batch][h][w][c] uint8 camera frames of any size (y2_detect_u8)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        b, h, w, c = frames.shape
+        if b != self.net.batch:
+            raise Y2Error("detect_u8: %d frames for a batch-%d network" % (b, self.net.batch))
+        l = self.last
+        cap = l.w * l.h * l.n
+        dets = np.zeros((self.net.batch, cap), dtype=DET_DTYPE)
+        counts = np.zeros(self.net.batch, dtype=np.int32)
+        if lib().y2_detect_u8(self.net, _ptr(frames), h, w, c, w * c, int(swap_rb), int(letterbox), thresh, nms,
+                              img_w, img_h, _ptr(dets), _ptr(counts), cap) != 0:
+            raise Y2Error("y2_detect_u8: " + _check())
+        return [dets[i, :min(int(counts[i]), cap)].copy() for i in range(self.net.batch)], counts
+
+    def ingest_u8(self, frames: np.ndarray, swap_rb: bool = True, letterbox: bool = False) -> None:
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        b, h, w, c = frames.shape
+        if b != self.net.batch:
+            raise Y2Error("ingest_u8: %d frames for a batch-%d network" % (b, self.net.batch))
+        if lib().y2_ingest_u8(self.net, _ptr(frames), h, w, c, w * c, int(swap_rb), int(letterbox)) != 0:
+            raise Y2Error("y2_ingest_u8: " + _check())
+
+    def validate_detector_frames(self, frames: np.ndarray, paths, orig_w, orig_h, prefix: str, eval: str = "voc",
+                                 names=None, map_: np.ndarray | None = None) -> None:
+        """validate_detector (detector.c:245) over in-memory network-sized frames [n][c][h][w]."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        n = frames.shape[0]
+        ow = np.ascontiguousarray(orig_w, dtype=np.int32)
+        oh = np.ascontiguousarray(orig_h, dtype=np.int32)
+        cpaths = (C.c_char_p * n)(*[p.encode() for p in paths])
+        cnames = (C.c_char_p * len(names))(*[s.encode() for s in names]) if names else None
+        mp = np.ascontiguousarray(map_, dtype=np.int32) if map_ is not None else None
+        if lib().y2_validate_detector_frames(self.net, _ptr(frames), n, cpaths, _ptr(ow), _ptr(oh), eval.encode(),
+                                             prefix.encode(), cnames, _ptr(mp) if mp is not None else None) != 0:
+            raise Y2Error("y2_validate_detector_frames: " + _check())
+
+    def validate_recall_frames(self, frames: np.ndarray, truth_per_frame) -> dict:
+        """validate_detector_recall (detector.c:371): truth_per_frame = list of [k][4] relative centre-form boxes."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        n = frames.shape[0]
+        first = np.zeros(n + 1, np.int32)
+        first[1:] = np.cumsum([len(t) for t in truth_per_frame])
+        truth = np.ascontiguousarray(np.concatenate([np.asarray(t, np.float32).reshape(-1, 4) for t in truth_per_frame] or
+                                                    [np.zeros((0, 4), np.float32)]), dtype=np.float32)
+        if truth.size == 0:
+            truth = np.zeros((1, 4), np.float32)
+        res = Recall()
+        if lib().y2_validate_recall_frames(self.net, _ptr(frames), n, _ptr(truth), _ptr(first), C.byref(res)) != 0:
+            raise Y2Error("y2_validate_recall_frames: " + _check())
+        return dict(total=res.total, correct=res.correct, proposals=res.proposals, avg_iou=res.avg_iou)
+
     def pull_layer_output(self, i: int) -> np.ndarray:
         l = self.net.layers[i]
         out = np.zeros(self.net.batch * l.outputs, dtype=np.float32)
@@ -435,6 +513,70 @@ def resize_image(im: np.ndarray, w: int, h: int) -> np.ndarray:
         raise Y2Error("resize_image: " + _check())
     arr = np.ctypeslib.as_array(out.data, shape=(c, h, w)).copy()
     L.free_image(out)
+    return arr
+
+
+class _CFile:
+    """FILE* from the C library, for the writers that take one (the reference's own signatures)."""
+    _libc = None
+
+    def __init__(self, path: str, mode: str = "w"):
+        if _CFile._libc is None:
+            _CFile._libc = C.CDLL(None)
+            _CFile._libc.fopen.restype = C.c_void_p
+            _CFile._libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+            _CFile._libc.fclose.argtypes = [C.c_void_p]
+        self.fp = _CFile._libc.fopen(path.encode(), mode.encode())
+        if not self.fp:
+            raise OSError("cannot open " + path)
+
+    def close(self):
+        if self.fp:
+            _CFile._libc.fclose(self.fp)
+            self.fp = None
+
+
+def write_detections(kind: str, paths, ident, boxes: np.ndarray, probs: np.ndarray, w: int, h: int) -> None:
+    """The reference's evaluation writers (detector.c:175-243) through this library: kind 'voc'
+    (print_detector_detections, one path per class), 'imagenet' (print_imagenet_detections), 'coco' (print_cocos)."""
+    L = lib()
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    probs = np.ascontiguousarray(probs, dtype=np.float32)
+    total, classes = probs.shape
+    rows = _rows(probs)
+    files = [_CFile(p, "a") for p in paths]
+    try:
+        if kind == "voc":
+            fps = (C.c_void_p * classes)(*[f.fp for f in files])
+            L.print_detector_detections(fps, str(ident).encode(), _ptr(boxes), rows, total, classes, w, h)
+        elif kind == "imagenet":
+            L.print_imagenet_detections(files[0].fp, int(ident), _ptr(boxes), rows, total, classes, w, h)
+        elif kind == "coco":
+            L.print_cocos(files[0].fp, str(ident).encode(), _ptr(boxes), rows, total, classes, w, h)
+        else:
+            raise ValueError(kind)
+    finally:
+        for f in files:
+            f.close()
+
+
+def letterbox_image(im: np.ndarray, w: int, h: int, into: np.ndarray | None = None) -> np.ndarray:
+    """image.c:1624 letterbox_image (into=None) / :1607 letterbox_image_into, on the GPU."""
+    L = lib()
+    im = np.ascontiguousarray(im, dtype=np.float32)
+    c, ih, iw = im.shape
+    src = Image(ih, iw, c, im.ctypes.data_as(C.POINTER(C.c_float)))
+    if into is None:
+        out = L.letterbox_image(src, w, h)
+        failed = L.y2_failed_and_clear()
+        arr = np.ctypeslib.as_array(out.data, shape=(c, h, w)).copy()
+        L.free_image(out)
+    else:
+        arr = np.ascontiguousarray(into, dtype=np.float32).copy()
+        L.letterbox_image_into(src, w, h, Image(h, w, c, arr.ctypes.data_as(C.POINTER(C.c_float))))
+        failed = L.y2_failed_and_clear()
+    if failed:
+        raise Y2Error("letterbox_image: " + _check())
     return arr
 
 

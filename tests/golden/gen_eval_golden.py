@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Golden vectors for the evaluation writers: runs the COMPILED REFERENCE's
+print_detector_detections / print_imagenet_detections (src_yolo2/detector.c:201-243, through
+oracle/_ref/ref_driver evalw) on seeded boxes/probabilities and stores inputs + the exact text they wrote
+in tests/golden/eval_writers.npz.  Needs /root/reference (via oracle/build_ref.sh); run in the build container:
+
+    python tests/golden/gen_eval_golden.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF_DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+OUT = os.path.join(ROOT, "tests", "golden", "eval_writers.npz")
+
+
+def main():
+    if not os.path.exists(REF_DRIVER):
+        sys.exit("oracle/_ref/ref_driver missing: run oracle/build_ref.sh where /root/reference exists")
+    rng = np.random.default_rng(20261004)
+    total, classes, w, h = 48, 6, 500, 375
+    boxes = np.empty((total, 4), np.float32)
+    boxes[:, 0] = rng.uniform(-20, w + 20, total)          # centres, some outside the image: clipping matters
+    boxes[:, 1] = rng.uniform(-20, h + 20, total)
+    boxes[:, 2] = rng.uniform(5, 300, total)
+    boxes[:, 3] = rng.uniform(5, 300, total)
+    probs = rng.uniform(0, 1, (total, classes)).astype(np.float32)
+    probs[rng.uniform(size=probs.shape) < 0.8] = 0          # NMS / threshold leave most entries zero
+    probs[3, 2] = np.float32(1e-7)                          # tiny but non-zero scores are still printed
+    probs[5, 1] = np.float32(0.005)
+    fix = {"boxes": boxes, "probs": probs, "w": w, "h": h, "id": "2007_000042", "imagenet_id": 7}
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = os.path.join(tmp, "in.bin")
+        np.concatenate([boxes.ravel(), probs.ravel()]).astype(np.float32).tofile(inp)
+        prefix = os.path.join(tmp, "out")
+        subprocess.check_call([REF_DRIVER, "evalw", inp, str(total), str(classes), str(w), str(h), fix["id"], prefix])
+        for j in range(classes):
+            fix["voc_c%d" % j] = np.frombuffer(open("%s_c%d.txt" % (prefix, j), "rb").read(), dtype=np.uint8)
+        fix["imagenet"] = np.frombuffer(open(prefix + "_imagenet.txt", "rb").read(), dtype=np.uint8)
+    np.savez_compressed(OUT, **fix)
+    print("wrote %s: %d voc lines, %d imagenet bytes" % (OUT, sum(bytes(fix["voc_c%d" % j]).count(b"\n") for j in range(classes)),
+                                                         fix["imagenet"].size))
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,25 @@ int main(int argc, char **argv)
     bool ok = t1.size() == t2.size();
     for (size_t i = 0; ok && i < t1.size(); ++i) ok = t1[i].track_id > 0 && t2[i].track_id > 0;
     std::printf("TRACK %d\n", ok ? 1 : 0);
+    // camera-frame entry: the same bytes through detect_frame (device ingest) and through the host conversion
+    // the reference's OpenCV glue does (hpp:94-141: v/255. into planes, BGR -> RGB) + detect(image_t)
+    {
+        const int w = im.w, h = im.h;
+        std::vector<unsigned char> bgr((size_t)w * h * 3);
+        std::vector<float> planes((size_t)w * h * 3);
+        for (int k = 0; k < 3; ++k) for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+            const unsigned char v = (unsigned char)(data[((size_t)k * h + y) * w + x] * 255.f);
+            bgr[((size_t)y * w + x) * 3 + (2 - k)] = v;
+            planes[((size_t)k * h + y) * w + x] = (float)(v / 255.);
+        }
+        image_t q = im; q.data = planes.data();
+        std::vector<bbox_t> a = det.detect(q, thresh), b = det.detect_frame(bgr.data(), w, h, 3, w * 3, thresh, true);
+        bool same = a.size() == b.size();
+        for (size_t i = 0; same && i < a.size(); ++i)
+            same = a[i].x == b[i].x && a[i].y == b[i].y && a[i].w == b[i].w && a[i].h == b[i].h && a[i].prob == b[i].prob &&
+                   a[i].obj_id == b[i].obj_id;
+        std::printf("FRAME %d %zu\n", same ? 1 : 0, b.size());
+    }
     try { Detector::load_image("/nonexistent.ppm"); std::printf("NOTHROW\n"); }
     catch (const std::exception &e) { std::printf("THROW %s\n", e.what()); }
     return 0;

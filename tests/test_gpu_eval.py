@@ -1,0 +1,126 @@
+"""validate_detector / validate_detector_recall over in-memory frames on the GPU, against the
+same per-image sequence run through the oracle (predict -> get_region_boxes -> do_nms[_sort] -> writer)."""
+import os
+
+import numpy as np
+import pytest
+
+from sr_object_detection_amd import darknet, synth, voc_eval
+from tests.helpers import load_golden, materialize
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_validate(oracle, cfg, wts, frames, ids, ow, oh, out_dir, names):
+    on = oracle.OracleNet(cfg, wts)
+    os.makedirs(out_dir, exist_ok=True)
+    paths = [os.path.join(out_dir, "comp4_det_test_%s.txt" % n) for n in names]
+    for p in paths:
+        open(p, "w").close()
+    for f in range(frames.shape[0]):
+        on.predict(frames[f:f + 1])
+        boxes, probs = on.region_boxes(0, 0.005, w=int(ow[f]), h=int(oh[f]))
+        post = oracle.do_nms_sort(boxes, probs, 0.45)
+        oracle.write_detections("voc", paths, ids[f], boxes, post, int(ow[f]), int(oh[f]))
+    on.close()
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_validate_detector_frames_matches_oracle(oracle, workdir, tmp_path, batch):
+    g = load_golden("mini_64_b3")
+    seed, gain = int(g["seed"]), float(g["head_gain"])
+    cfg1, wts, _ = materialize(workdir, "mini", 64, 1, seed, gain)
+    cfgb, _, _ = materialize(workdir, "mini", 64, batch, seed, gain)
+    n = 5                                                        # not a multiple of the batch: the tail is padded
+    frames = synth.image_batch(n, 3, 64, 64, seed=4242)
+    ow = np.array([500, 640, 333, 64, 1024], np.int32)
+    oh = np.array([375, 480, 500, 64, 768], np.int32)
+    paths = ["/data/VOC/JPEGImages/2007_%06d.jpg" % i for i in range(n)]
+    ids = ["2007_%06d" % i for i in range(n)]
+    net = darknet.Network.parse_network_cfg(cfgb)
+    net.load_weights(wts)
+    classes = net.last.classes
+    names = ["cls%d" % j for j in range(classes)]
+    want_dir = str(tmp_path / "want")
+    _oracle_validate(oracle, cfg1, wts, frames, ids, ow, oh, want_dir, names)
+    # strict mode: reference-order convolution, so the text must be identical byte for byte
+    net.set_strict(True)
+    strict_dir = str(tmp_path / "strict")
+    os.makedirs(strict_dir)
+    net.validate_detector_frames(frames, paths, ow, oh, strict_dir, "voc", names)
+    lines = 0
+    for nme in names:
+        a = open(os.path.join(strict_dir, "comp4_det_test_%s.txt" % nme), "rb").read()
+        b = open(os.path.join(want_dir, "comp4_det_test_%s.txt" % nme), "rb").read()
+        assert a == b
+        lines += a.count(b"\n")
+    assert lines > 20
+    # MFMA path: same detections within tolerance -> mAP-equivalent to the CPU run
+    net.set_strict(False)
+    fast_dir = str(tmp_path / "fast")
+    os.makedirs(fast_dir)
+    net.validate_detector_frames(frames, paths, ow, oh, fast_dir, "voc", names)
+    m, aps = voc_eval.map_equiv(fast_dir, want_dir, names, min_score=0.05)
+    assert m == 1.0 and len(aps) > 0
+    # the other two writers run through the same loop
+    coco_dir = str(tmp_path / "coco")
+    os.makedirs(coco_dir)
+    net.validate_detector_frames(frames, ["COCO_val2014_%012d.jpg" % i for i in range(n)], ow, oh, coco_dir, "coco")
+    import json
+    rows = json.load(open(os.path.join(coco_dir, "coco_results.json")))
+    assert len(rows) == lines and {r["image_id"] for r in rows} <= set(range(n))
+    net.free()
+
+
+def test_validate_detector_frames_errors(workdir, tmp_path):
+    cfg, wts, x = materialize(workdir, "mini", 32, 1, 1)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    with pytest.raises(darknet.Y2Error):                         # voc writer without names
+        net.validate_detector_frames(x, ["a.jpg"], [32], [32], str(tmp_path), "voc", None)
+    with pytest.raises(darknet.Y2Error):                         # unwritable prefix
+        net.validate_detector_frames(x, ["a.jpg"], [32], [32], str(tmp_path / "missing"), "coco")
+    net.free()
+
+
+def test_validate_recall_frames_matches_oracle(oracle, workdir):
+    g = load_golden("mini_64_b3")
+    seed, gain = int(g["seed"]), float(g["head_gain"])
+    cfg1, wts, _ = materialize(workdir, "mini", 64, 1, seed, gain)
+    cfg2, _, _ = materialize(workdir, "mini", 64, 2, seed, gain)
+    n = 3
+    frames = synth.image_batch(n, 3, 64, 64, seed=999)
+    on = oracle.OracleNet(cfg1, wts)
+    # truth = a few of the oracle's own confident boxes (jittered), plus one box nothing matches
+    truth, want = [], dict(total=0, correct=0, proposals=0, avg_iou=np.float32(0))
+    per_frame = []
+    for f in range(n):
+        on.predict(frames[f:f + 1])
+        boxes, probs = on.region_boxes(0, 0.2, only_objectness=1)
+        post = oracle.do_nms(boxes, probs[:, :1].copy(), 0.4)
+        per_frame.append((boxes, post[:, 0]))
+        top = np.argsort(-post[:, 0])[:2]
+        t = [boxes[k] * np.array([1, 1, 1.05, 0.95], np.float32) for k in top if post[k, 0] > 0.2]
+        t.append(np.array([0.9, 0.05, 0.02, 0.02], np.float32))
+        truth.append(np.array(t, np.float32))
+    on.close()
+    for f in range(n):
+        boxes, score = per_frame[f]
+        want["proposals"] += int((score > 0.2).sum())
+        for t in truth[f]:
+            want["total"] += 1
+            best = np.float32(0)
+            for k in np.nonzero(score > 0.2)[0]:
+                iou = np.float32(oracle.box_iou(boxes[k], t))
+                if iou > best:
+                    best = iou
+            want["avg_iou"] = np.float32(want["avg_iou"] + best)
+            want["correct"] += int(best > 0.5)
+    net = darknet.Network.parse_network_cfg(cfg2)
+    net.load_weights(wts)
+    net.set_strict(True)
+    got = net.validate_recall_frames(frames, truth)
+    assert (got["total"], got["correct"], got["proposals"]) == (want["total"], want["correct"], want["proposals"])
+    assert got["correct"] > 0 and got["total"] > got["correct"]
+    assert abs(got["avg_iou"] - float(want["avg_iou"])) < 1e-5
+    net.free()

@@ -1,0 +1,108 @@
+"""Frame ingest on the device: u8 -> planes, BGR->RGB, resize / letterbox, and the fused
+camera-frame entry y2_detect_u8, checked against the oracle's restatement of yolo_v2_class.hpp:94-141
+and image.c:1087,1601-1645,1950-1992.
+
+Parity note: the reference's image.c does not compile without OpenCV, so these
+oracle functions are a line-by-line restatement that no run of the reference pins ("parity unpinned" for
+the ingest helpers; the network/decode/NMS behind them are pinned by tests/golden)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sr_object_detection_amd import darknet, synth
+from tests.helpers import load_golden, materialize
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(b, h, w, c, seed=5):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=(b, h, w, c), dtype=np.uint8)
+
+
+def _u8_to_planes_dev(frames, planes, swap, step=None):
+    """call y2h_u8_to_planes directly (thin C-ABI layer), optionally with a padded row pitch"""
+    L = darknet.lib()
+    b, h, w, c = frames.shape
+    step = step or w * c
+    raw = np.zeros((b, h, step), np.uint8)
+    raw[:, :, :w * c] = frames.reshape(b, h, w * c)
+    d_src, d_dst = C.c_void_p(), C.c_void_p()
+    assert L.y2h_malloc(C.byref(d_src), raw.nbytes) == 0 and L.y2h_malloc(C.byref(d_dst), b * planes * h * w * 4) == 0
+    out = np.zeros((b, planes, h, w), np.float32)
+    assert L.y2h_memcpy_h2d(d_src, raw.ctypes.data, raw.nbytes, None) == 0
+    assert L.y2h_u8_to_planes(d_src, b, h, w, c, step, step * h, planes, int(swap), d_dst, None) == 0
+    assert L.y2h_memcpy_d2h(out.ctypes.data, d_dst, out.nbytes, None) == 0
+    L.y2h_free(d_src); L.y2h_free(d_dst)
+    return out
+
+
+@pytest.mark.parametrize("c,planes,swap,pad", [(3, 3, True, 0), (3, 3, False, 5), (4, 3, True, 8), (4, 4, True, 0), (1, 1, True, 3)])
+def test_u8_to_planes_bitwise(oracle, c, planes, swap, pad):
+    fr = _frames(2, 37, 53, c)
+    got = _u8_to_planes_dev(fr, planes, swap, step=53 * c + pad)
+    for b in range(2):
+        assert np.array_equal(got[b], oracle.u8_to_planes(fr[b], planes, swap))
+    # every byte value maps to the reference's double division rounded once to fp32
+    allv = np.arange(256, dtype=np.uint8).reshape(1, 1, 256, 1)
+    assert np.array_equal(_u8_to_planes_dev(allv, 1, False)[0, 0, 0], (np.arange(256) / 255.0).astype(np.float32))
+
+
+@pytest.mark.parametrize("ih,iw,h,w", [(48, 64, 96, 96), (64, 48, 96, 96), (33, 97, 64, 128), (50, 50, 32, 32), (17, 200, 416, 416)])
+def test_letterbox_image_bitwise(oracle, ih, iw, h, w):
+    x = synth.image_batch(1, 3, ih, iw, seed=77)[0]
+    want = oracle.letterbox_image(x, w, h)
+    got = darknet.letterbox_image(x, w, h)
+    assert np.array_equal(got, want)
+    assert (got == .5).any() or (ih * w == iw * h)          # the bars are there unless the aspect already matches
+    box = synth.image_batch(1, 3, h, w, seed=78)[0]
+    assert np.array_equal(darknet.letterbox_image(x, w, h, into=box), oracle.letterbox_image(x, w, h, into=box))
+
+
+def test_letterbox_errors():
+    with pytest.raises(darknet.Y2Error):
+        darknet.letterbox_image(np.zeros((3, 1, 900), np.float32), 4, 4)     # (ih*w)/iw == 0 -> degenerate
+
+
+@pytest.mark.parametrize("letterbox,fh,fw,c", [(False, 64, 64, 3), (False, 48, 80, 4), (True, 48, 80, 3), (True, 90, 40, 4)])
+def test_detect_u8_equals_float_path(oracle, workdir, letterbox, fh, fw, c):
+    """bytes in -> detections out equals: oracle ingest (u8->planes, swap, resize/letterbox) + the float entry"""
+    g = load_golden("mini_64_b3")
+    cfg, wts, _ = materialize(workdir, "mini", 64, 3, int(g["seed"]), float(g["head_gain"]))
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    fr = _frames(3, fh, fw, c, seed=11)
+    planes = [oracle.u8_to_planes(f, 3, True) for f in fr]
+    if (fh, fw) != (64, 64):
+        planes = [oracle.letterbox_image(p, 64, 64) if letterbox else oracle.resize_image(p, 64, 64) for p in planes]
+    x = np.stack(planes)
+    thresh, nms = 0.05, 0.4
+    want, wc = net.detect(x, thresh, nms)
+    got, gc = net.detect_u8(fr, thresh, nms, swap_rb=True, letterbox=letterbox)
+    assert np.array_equal(wc, gc) and int(gc.sum()) > 0
+    for a, b in zip(want, got):
+        assert a.tobytes() == b.tobytes()
+    # and the network input it built is bit-identical to the oracle's
+    net.ingest_u8(fr, swap_rb=True, letterbox=letterbox)
+    L = darknet.lib()
+    L.y2_forward_device(net.net, None)
+    ref = darknet.Network.parse_network_cfg(cfg)
+    ref.load_weights(wts)
+    ref.network_predict(x)
+    assert np.array_equal(net.pull_layer_output(net.n - 2), ref.pull_layer_output(net.n - 2))
+    ref.free()
+    net.free()
+
+
+def test_detect_u8_rejects_bad_geometry(workdir):
+    cfg, wts, _ = materialize(workdir, "mini", 32, 2, 1)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    with pytest.raises(darknet.Y2Error):
+        net.detect_u8(_frames(3, 32, 32, 3), 0.2, 0.4)          # batch mismatch
+    with pytest.raises(darknet.Y2Error):
+        net.detect_u8(_frames(2, 32, 32, 2), 0.2, 0.4)          # fewer channels than the network reads
+    net.free()

@@ -79,6 +79,8 @@ def test_cpp_detector_matches_oracle(oracle, workdir):
         assert all(abs(int(b[i]) - int(w[k])) <= 1 for i, k in enumerate(("x", "y", "w", "h")))
         assert abs(float(b[4]) - float(w["prob"])) < 1e-4 and int(b[5]) == int(w["obj_id"]) and int(b[6]) == 0
     assert "TRACK 1" in lines
+    frame_line = [l for l in lines if l.startswith("FRAME")][0].split()
+    assert frame_line[1] == "1" and int(frame_line[2]) > 0      # detect_frame(u8) == host conversion + detect(image_t)
     assert any(l.startswith("THROW file not found") for l in lines)
     mean = [l for l in lines if l.startswith("MEAN")][0].split()
     assert int(mean[3]) == len(want)         # third use_mean call: the average of three identical frames
