@@ -46,8 +46,10 @@ WORKLOADS = {
     "tiny416_b1": dict(net="tiny-yolo-voc", size=416, batch=1),
     # configs[3] per-GPU share (64 frames over 8 GPUs), synthetic 9418-node tree (cfg/9k.tree is corrupt)
     "yolo9000_544_b8": dict(net="yolo9000", size=544, batch=8),
-    # configs[4] network in fp32 (the fp16 path is not built yet)
+    # configs[4]: darknet19_448 classifier, fp16 storage / fp32 accumulate on the fp16 matrix cores; and in fp32
+    "darknet19_448_b128_f16": dict(net="darknet19", size=448, batch=128, half=True),
     "darknet19_448_b32": dict(net="darknet19", size=448, batch=32),
+    "yolo608_b32_f16": dict(net="yolo", size=608, batch=32, half=True),
 }
 
 
@@ -61,6 +63,7 @@ def write_cfg(tmp: str, name: str, size: int, batch: int, fname: str = "net.cfg"
     cfg = os.path.join(tmp, fname)
     open(cfg, "w").write(zoo.cfg_text(name, size, size, batch, tree_path=tree))
     return cfg
+PEAK_FP16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_f16: 32 cycles per 32768 FLOP per SIMD -> 16x the fp32 rate
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 THRESH, NMS = 0.2, 0.4             # Detector defaults (yolo_v2_class.hpp:45,50)
 
@@ -174,12 +177,15 @@ def main():
 
     wl = WORKLOADS[args.workload]
     name, size, batch = wl["net"], wl["size"], wl["batch"]
+    half = bool(wl.get("half"))
+    peak = PEAK_FP16_MFMA_TFLOPS if half else PEAK_FP32_MFMA_TFLOPS
     tmp = tempfile.mkdtemp(prefix="y2bench_r%d_" % rank)
     cfg = write_cfg(tmp, name, size, batch)
     layers = zoo.resolve(name, size)
 
     L = darknet.lib()
     net = darknet.Network.parse_network_cfg(cfg, gpu=device_index)
+    net.set_half(half)
     wts = os.path.join(tmp, "net.weights")
     if rank == 0:
         synth.write_weights(wts, layers, args.seed)
@@ -256,8 +262,8 @@ def main():
         roof = None
         if dom:
             ach = per_kernel_flops[dom] / (per_kernel_ms[dom] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom, args.workload),
+            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), traffic=pmc_traffic(dom, args.workload),
                         launches_per_step=per_kernel_launches[dom] // max(args.steps, 1),
                         avg_launch_ms=round(per_kernel_ms[dom] / per_kernel_launches[dom], 4),
                         avg_launch_gflop=round(per_kernel_flops[dom] / per_kernel_launches[dom] / 1e9, 3))
@@ -265,10 +271,11 @@ def main():
         cfg_b1 = write_cfg(tmp, name, size, 1, "net_b1.cfg")
         cpu = cpu_baseline(cfg_b1, wts, size, args.cpu_iters, tmp)
         line = {
-            "metric": "images/sec YOLOv2 608x608 fp32" if size == 608 else "images/sec YOLOv2 %dx%d fp32" % (size, size),
+            "metric": "images/sec YOLOv2 608x608 fp32" if (size == 608 and not half) else
+                      "images/sec %s %dx%d %s" % (name, size, size, "fp16" if half else "fp32"),
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16" if half else "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d batch %d per GPU: forward + region decode + NMS(%.1f) + collect, "
                                    "%s" % (name + ".cfg", size, size, batch, NMS,
                                                    "inputs in host memory (PCIe-inclusive)" if args.host_input

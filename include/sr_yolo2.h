@@ -254,6 +254,11 @@ void y2_set_strict(network *net, int strict);
 void y2_set_fusion(network *net, int on);
 /* The packed, kernel-layout weight arena (one allocation; what a multi-GPU launcher broadcasts). */
 int y2_weights_arena(network *net, void **dev_ptr, size_t *bytes);
+/* fp16 storage mode (no reference counterpart; BASELINE configs[4]): activations and packed weights are
+ * IEEE half in HBM, convolutions accumulate in fp32 on the fp16 matrix cores, batch-norm is folded into one
+ * fp32 fma, the region / avgpool / softmax heads stay fp32.  Takes effect at the next forward (the plan is
+ * rebuilt).  Ignored while strict mode is on.  Env Y2_FP16=1 turns it on for every network. */
+void y2_set_half(network *net, int on);
 /* Declare the arena contents valid although load_weights was not called on this process
  * (e.g. it was filled by an RCCL broadcast from rank 0). */
 void y2_weights_resident(network *net);

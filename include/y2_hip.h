@@ -110,6 +110,12 @@ typedef struct y2h_conv {
     float        *y;             /* device, NHWC (already offset to the first channel) */
     float        *ws;            /* device scratch for split-K partial sums, or 0      */
     size_t        ws_bytes;      /* size of ws; see y2h_conv_workspace_bytes           */
+    /* fp16 storage (engine extension, the reference is fp32 only): */
+    int           x_f16;         /* 1: x and w_packed hold IEEE half (ldx counts halves); fp32 accumulate on
+                                    v_mfma_f32_32x32x16_f16; the epilogue is y = act(acc*alpha + beta)   */
+    int           y_f16;         /* 1: y is stored as half (ldy counts halves)         */
+    const float  *alpha;         /* device [n]  scale/(sqrt(var)+1e-6)  (1 without BN)  */
+    const float  *beta;          /* device [n]  bias - mean*alpha                       */
 } y2h_conv;
 
 /* which kernel y2h_conv_forward would pick: 1 = MFMA implicit GEMM, 0 = direct VALU */
@@ -138,6 +144,17 @@ int y2h_reorg(const float *x, int ldx, float *y, int ldy, int batch, int h, int 
 int y2h_avgpool(const float *x, int ldx, float *y, int batch, int h, int w, int c, y2h_stream s);
 /* rows of `n` floats: softmax with temperature (blas.c:205); in/out may alias */
 int y2h_softmax_rows(const float *x, float *y, long rows, int n, float temp, y2h_stream s);
+
+/* ---- half-storage variants (engine extension: BASELINE configs[4]; void* = IEEE half, ld in halves) ---- */
+int y2h_maxpool_f16(const void *x, int ldx, void *y, int ldy, int batch, int h, int w, int c,
+                    int size, int stride, int pad, int out_h, int out_w, y2h_stream s);
+int y2h_reorg_f16(const void *x, int ldx, void *y, int ldy, int batch, int h, int w, int c,
+                  int stride, int reverse, y2h_stream s);
+int y2h_copy_channels_f16(const void *src, int ld_src, void *dst, int ld_dst, int c, long npix, y2h_stream s);
+int y2h_avgpool_f16(const void *x, int ldx, float *y, int batch, int h, int w, int c, y2h_stream s);  /* fp32 sum and result */
+int y2h_nhwc_f16_to_nchw(const void *src, int ld, float *dst, int n, int c, int h, int w, y2h_stream s);
+int y2h_f32_to_f16(const float *src, void *dst, long n, y2h_stream s);
+int y2h_f16_to_f32(const void *src, float *dst, long n, y2h_stream s);
 
 /* ---- region head ---- */
 /* x: last conv output NHWC [batch][h*w][ldx] holding num*(coords+1+classes) channels.

@@ -42,6 +42,7 @@ int y2_engine_create(network *net)
     e->weights_dirty = 1;
     e->strict = (st && atoi(st) != 0) ? 1 : 0;
     e->fusion = getenv("Y2_NO_FUSE") ? 0 : 1;
+    { const char *hf = getenv("Y2_FP16"); e->half = (hf && atoi(hf) != 0) ? 1 : 0; }
     e->n_layers = net->n;
     e->out_layer = y2_out_layer(net);
     for (i = 0; i < net->n; ++i) {
@@ -94,6 +95,7 @@ static void free_plan(network *net)
         y2h_free(d->d_flat); d->d_flat = NULL;
         d->placed_in = -1; d->alias_of = -1; d->copy_mask = 0;
         d->fused_pool = 0; d->fused_into = -1;
+        d->out_half = 0;
     }
     y2h_free(e->d_in_nchw); e->d_in_nchw = NULL;
     y2h_free(e->d_in_nhwc); e->d_in_nhwc = NULL;
@@ -177,10 +179,16 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     c->ws = e->d_ws;
     c->ws_bytes = e->ws_bytes;
     c->y = d->out;
+    c->y_f16 = d->out_half;
+    c->x_f16 = (i > 0) ? ld_of(&net->layers[i - 1])->out_half : 0;     /* the network input itself is fp32 */
     if (e->arena) {
         c->w_packed = (const float *)(e->arena + d->off_w_packed);
         c->w_ref = d->has_w_ref ? (const float *)(e->arena + d->off_w_ref) : NULL;
         c->bias = (const float *)(e->arena + d->off_bias);
+        if (c->x_f16) {
+            c->alpha = (const float *)(e->arena + d->off_alpha);
+            c->beta = (const float *)(e->arena + d->off_beta);
+        }
         if (l->batch_normalize) {
             c->mean = (const float *)(e->arena + d->off_mean);
             c->scale = (const float *)(e->arena + d->off_scale);
@@ -204,6 +212,34 @@ static int upload_small(void **dst, const void *src, size_t bytes, y2h_stream s)
     return y2h_stream_sync(s);
 }
 
+/* fp32 -> IEEE half, round to nearest even (what the device's v_cvt_f16_f32 does) */
+static unsigned short f32_to_f16_rne(float f)
+{
+    unsigned int x, sign, mant;
+    int exp;
+    memcpy(&x, &f, sizeof x);
+    sign = (x >> 16) & 0x8000u;
+    exp = (int)((x >> 23) & 0xff) - 127 + 15;
+    mant = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (unsigned short)(sign | 0x7c00u | (mant ? 0x200u : 0));   /* inf / nan */
+    if (exp >= 31) return (unsigned short)(sign | 0x7c00u);                                          /* overflow */
+    if (exp <= 0) {                                                                                  /* subnormal / zero */
+        unsigned int shift, half, rem;
+        if (exp < -10) return (unsigned short)sign;
+        mant |= 0x800000u;
+        shift = (unsigned int)(14 - exp);
+        half = mant >> shift;
+        rem = mant & ((1u << shift) - 1);
+        if (rem > (1u << (shift - 1)) || (rem == (1u << (shift - 1)) && (half & 1))) ++half;
+        return (unsigned short)(sign | half);
+    }
+    {
+        unsigned int half = ((unsigned int)exp << 10) | (mant >> 13), rem = mant & 0x1fffu;
+        if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) ++half;      /* may carry into the exponent: correct */
+        return (unsigned short)(sign | half);
+    }
+}
+
 static int upload_weights(network *net)
 {
     y2_engine *e = y2_engine_of(net);
@@ -214,6 +250,7 @@ static int upload_weights(network *net)
         const y2_ldev *d = ld_of(l);
         float *wp, *b;
         int K, co, ci, kh, kw, f;
+        const int w_half = (i > 0) && ld_of(&net->layers[i - 1])->out_half;   /* half input -> half weights */
         if (l->type != CONVOLUTIONAL) continue;
         K = l->size * l->size * l->c;
         wp = (float *)(host + d->off_w_packed);
@@ -221,9 +258,24 @@ static int upload_weights(network *net)
         for (co = 0; co < l->n; ++co)
             for (ci = 0; ci < l->c; ++ci)
                 for (kh = 0; kh < l->size; ++kh)
-                    for (kw = 0; kw < l->size; ++kw)
-                        wp[(size_t)co * K + (size_t)(kh * l->size + kw) * l->c + ci] =
-                            l->weights[(((size_t)co * l->c + ci) * l->size + kh) * l->size + kw];
+                    for (kw = 0; kw < l->size; ++kw) {
+                        const size_t dst = (size_t)co * K + (size_t)(kh * l->size + kw) * l->c + ci;
+                        const float v = l->weights[(((size_t)co * l->c + ci) * l->size + kh) * l->size + kw];
+                        if (w_half) ((unsigned short *)wp)[dst] = f32_to_f16_rne(v);
+                        else wp[dst] = v;
+                    }
+        if (w_half) {
+            /* folded batch-norm for the fp16 kernels: y = act(acc*alpha + beta), constants evaluated in double */
+            float *al = (float *)(host + d->off_alpha), *be = (float *)(host + d->off_beta);
+            for (f = 0; f < l->n; ++f) {
+                double a = 1.0, bb = l->biases[f];
+                if (l->batch_normalize) {
+                    a = (double)l->scales[f] / (sqrt((double)l->rolling_variance[f]) + (double).000001f);
+                    bb = (double)l->biases[f] - (double)l->rolling_mean[f] * a;
+                }
+                al[f] = (float)a; be[f] = (float)bb;
+            }
+        }
         if (d->has_w_ref) memcpy(host + d->off_w_ref, l->weights, (size_t)l->n * K * sizeof(float));
         b = (float *)(host + d->off_bias);
         memcpy(b, l->biases, l->n * sizeof(float));
@@ -303,13 +355,44 @@ int y2_engine_build(network *net)
             ld_of(m)->fused_into = i;
         }
     }
+    /* pass 1c: fp16 storage (y2_set_half): image-like activations are half, heads stay fp32 */
+    if (e->half && !e->strict) {
+        for (i = 0; i < net->n; ++i) {
+            layer *l = &net->layers[i];
+            y2_ldev *d = ld_of(l), *pd = i > 0 ? ld_of(&net->layers[i - 1]) : NULL;
+            switch (l->type) {
+            case CONVOLUTIONAL:
+                /* the conv feeding a region head writes fp32: the head's logistic/softmax/exp run in fp32 */
+                d->out_half = !(i + 1 < net->n && net->layers[i + 1].type == REGION);
+                break;
+            case MAXPOOL: case REORG:
+                if (!pd || !pd->out_half) { y2_fail("fp16 mode: layer %d (%s) needs a half-precision producer", i, get_layer_string(l->type)); return -1; }
+                d->out_half = 1;
+                break;
+            case ROUTE:
+                if (l->n == 1) d->out_half = ld_of(&net->layers[l->input_layers[0]])->out_half;
+                else {
+                    for (k = 0; k < l->n; ++k)
+                        if (!ld_of(&net->layers[l->input_layers[k]])->out_half) { y2_fail("fp16 mode: route layer %d mixes fp32 and half inputs", i); return -1; }
+                    d->out_half = 1;
+                }
+                break;
+            case REGION: case SOFTMAX:
+                if (pd && pd->out_half) { y2_fail("fp16 mode: layer %d (%s) needs an fp32 producer (a convolutional or avgpool layer)", i, get_layer_string(l->type)); return -1; }
+                break;
+            case COST: d->out_half = pd ? pd->out_half : 0; break;
+            default: break;
+            }
+        }
+        if (net->n > 0 && net->layers[0].type != CONVOLUTIONAL) { y2_fail("fp16 mode: the first layer must be convolutional"); return -1; }
+    }
     /* pass 2: allocate.  Routes first (their sources point into them). */
     for (i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
         y2_ldev *d = ld_of(l);
         if (l->type == ROUTE && l->n >= 2) {
             d->out_floats = (size_t)l->batch * l->out_h * l->out_w * l->out_c;
-            HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * sizeof(float)));
+            HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * (d->out_half ? 2 : 4)));
             d->out = d->out_alloc;
             d->out_ld = l->out_c;
         }
@@ -326,11 +409,11 @@ int y2_engine_build(network *net)
                 y2_ldev *rd = ld_of(r);
                 int choff = 0;
                 for (k = 0; k < r->n && r->input_layers[k] != i; ++k) choff += net->layers[r->input_layers[k]].out_c;
-                d->out = rd->out + choff;
+                d->out = d->out_half ? (float *)((unsigned short *)rd->out + choff) : rd->out + choff;
                 d->out_ld = r->out_c;
             } else {
                 d->out_floats = (size_t)l->batch * l->out_h * l->out_w * l->out_c;
-                HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * sizeof(float)));
+                HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * (d->out_half ? 2 : 4)));
                 d->out = d->out_alloc;
                 d->out_ld = l->out_c;
             }
@@ -462,12 +545,14 @@ int y2_engine_build(network *net)
         y2h_conv c;
         const float *x; int ldx;
         size_t wbytes;
+        int w_half;
         if (l->type != CONVOLUTIONAL) continue;
         if (l->activation != LINEAR && l->activation != LEAKY && l->activation != LOGISTIC && l->activation != RELU) {
             y2_fail("layer %d: activation %d is not implemented on the device", i, (int)l->activation);
             return -1;
         }
         wbytes = (size_t)l->n * l->size * l->size * l->c * sizeof(float);
+        w_half = (i > 0) && ld_of(&net->layers[i - 1])->out_half;
         input_view(net, i, &x, &ldx);
         conv_desc(net, i, &c, x, ldx);
         c.w_packed = (const float *)(uintptr_t)256;       /* alignment stand-in for the query */
@@ -477,15 +562,19 @@ int y2_engine_build(network *net)
             y2_ldev *md = ld_of(&net->layers[i + 1]);
             d->fused_pool = 0; md->fused_into = -1; md->kernel = "maxpool_nhwc";
             d->out_floats = (size_t)l->batch * l->out_h * l->out_w * l->out_c;
-            HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * sizeof(float)));
+            HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * (d->out_half ? 2 : 4)));
             d->out = d->out_alloc; d->out_ld = l->out_c;
             conv_desc(net, i, &c, x, ldx);
             c.w_packed = (const float *)(uintptr_t)256;
         }
         d->has_w_ref = !d->uses_mfma;
-        d->off_w_packed = off; off = align_up(off + wbytes, 256);
+        d->off_w_packed = off; off = align_up(off + (w_half ? wbytes / 2 : wbytes), 256);
         if (d->has_w_ref) { d->off_w_ref = off; off = align_up(off + wbytes, 256); }
         d->off_bias = off; off = align_up(off + l->n * sizeof(float), 64);
+        if (w_half) {
+            d->off_alpha = off; off = align_up(off + l->n * sizeof(float), 64);
+            d->off_beta = off; off = align_up(off + l->n * sizeof(float), 64);
+        }
         if (l->batch_normalize) {
             d->off_mean = off; off = align_up(off + l->n * sizeof(float), 64);
             d->off_scale = off; off = align_up(off + l->n * sizeof(float), 64);
@@ -516,7 +605,7 @@ int y2_engine_build(network *net)
         HIPCALL(y2h_malloc((void **)&e->arena, off));
         if (!e->weights_external) e->weights_dirty = 1;
     }
-    if (e->built_strict != e->strict) e->weights_dirty = e->weights_external ? e->weights_dirty : 1;
+    if (e->built_strict != e->strict || e->built_half != e->half) e->weights_dirty = e->weights_external ? e->weights_dirty : 1;
     /* timing events */
     if (e->n_ev != net->n + 1) {
         if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
@@ -527,6 +616,7 @@ int y2_engine_build(network *net)
     e->built = 1;
     e->built_batch = net->batch; e->built_w = net->w; e->built_h = net->h; e->built_strict = e->strict;
     e->built_fusion = e->fusion;
+    e->built_half = e->half;
     if (e->weights_dirty && !e->weights_external && upload_weights(net) != 0) return -1;
     return 0;
 }
@@ -536,7 +626,7 @@ static int ensure_built(network *net)
     y2_engine *e = y2_engine_of(net);
     if (!e) { y2_fail("network has no engine (was it built by parse_network_cfg?)"); return -1; }
     if (!e->built || e->built_batch != net->batch || e->built_w != net->w || e->built_h != net->h ||
-        e->built_strict != e->strict || e->built_fusion != e->fusion) {
+        e->built_strict != e->strict || e->built_fusion != e->fusion || e->built_half != e->half) {
         if (y2_engine_build(net) != 0) return -1;
     } else {
         HIPCALL(y2h_set_device(e->device));
@@ -574,11 +664,18 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
         } break;
         case MAXPOOL:
             if (d->fused_into >= 0) break;       /* already produced by the conv before it */
-            HIPCALL(y2h_maxpool(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->size, l->stride, l->pad,
-                                l->out_h, l->out_w, e->stream));
+            if (d->out_half)
+                HIPCALL(y2h_maxpool_f16(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->size, l->stride, l->pad,
+                                        l->out_h, l->out_w, e->stream));
+            else
+                HIPCALL(y2h_maxpool(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->size, l->stride, l->pad,
+                                    l->out_h, l->out_w, e->stream));
             break;
         case REORG:
-            HIPCALL(y2h_reorg(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->stride, l->reverse, e->stream));
+            if (d->out_half)
+                HIPCALL(y2h_reorg_f16(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->stride, l->reverse, e->stream));
+            else
+                HIPCALL(y2h_reorg(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->stride, l->reverse, e->stream));
             break;
         case ROUTE:
             if (l->n >= 2 && d->copy_mask) {
@@ -586,7 +683,10 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
                 for (k = 0; k < l->n; ++k) {
                     layer *src = &net->layers[l->input_layers[k]];
                     y2_ldev *sd = ld_of(src);
-                    if (d->copy_mask & (1u << k))
+                    if ((d->copy_mask & (1u << k)) && d->out_half)
+                        HIPCALL(y2h_copy_channels_f16(sd->out, sd->out_ld, (unsigned short *)d->out + choff, d->out_ld, src->out_c,
+                                                      (long)l->batch * l->out_h * l->out_w, e->stream));
+                    else if (d->copy_mask & (1u << k))
                         HIPCALL(y2h_copy_channels(sd->out, sd->out_ld, d->out + choff, d->out_ld, src->out_c,
                                                   (long)l->batch * l->out_h * l->out_w, e->stream));
                     choff += src->out_c;
@@ -599,7 +699,10 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
                                        t ? t->groups : 0, d->d_tree_gsize, d->d_tree_goff, e->stream));
         } break;
         case AVGPOOL:
-            HIPCALL(y2h_avgpool(x, ldx, d->d_flat, l->batch, l->h, l->w, l->c, e->stream));
+            if (i > 0 && ld_of(&net->layers[i - 1])->out_half)
+                HIPCALL(y2h_avgpool_f16(x, ldx, d->d_flat, l->batch, l->h, l->w, l->c, e->stream));
+            else
+                HIPCALL(y2h_avgpool(x, ldx, d->d_flat, l->batch, l->h, l->w, l->c, e->stream));
             break;
         case SOFTMAX: {
             /* the input of a softmax layer is a flat [batch][inputs] vector; an image-like producer
@@ -632,7 +735,10 @@ int y2_engine_fetch_output(network *net)
     const float *src;
     if (l->type == REGION || l->type == AVGPOOL || l->type == SOFTMAX) src = d->out;
     else {
-        HIPCALL(y2h_nhwc_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
+        if (d->out_half)
+            HIPCALL(y2h_nhwc_f16_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
+        else
+            HIPCALL(y2h_nhwc_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
         src = e->d_out_nchw;
     }
     HIPCALL(y2h_memcpy_d2h(e->h_out, src, e->out_floats * sizeof(float), e->stream));
@@ -680,6 +786,12 @@ void y2_set_strict(network *net, int strict)
 {
     y2_engine *e = y2_engine_of(net);
     if (e) e->strict = strict ? 1 : 0;
+}
+
+void y2_set_half(network *net, int on)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (e) e->half = on ? 1 : 0;
 }
 
 void y2_set_fusion(network *net, int on)
@@ -756,7 +868,8 @@ int y2_pull_layer_output(network net, int i, float *dst)
         return 0;
     }
     HIPCALL(y2h_malloc((void **)&tmp, n * sizeof(float)));
-    if (y2h_nhwc_to_nchw(d->out, d->out_ld, tmp, l->batch, l->out_c, l->out_h, l->out_w, e->stream) != 0 ||
+    if ((d->out_half ? y2h_nhwc_f16_to_nchw(d->out, d->out_ld, tmp, l->batch, l->out_c, l->out_h, l->out_w, e->stream)
+                     : y2h_nhwc_to_nchw(d->out, d->out_ld, tmp, l->batch, l->out_c, l->out_h, l->out_w, e->stream)) != 0 ||
         y2h_memcpy_d2h(dst, tmp, n * sizeof(float), e->stream) != 0 || y2h_stream_sync(e->stream) != 0) {
         y2h_free(tmp);
         y2_fail("y2_pull_layer_output: %s", y2h_last_error());

@@ -25,6 +25,8 @@ typedef struct y2_ldev {
     int uses_mfma;
     int fused_pool;            /* conv: the following 2x2/2 maxpool runs in this conv's epilogue */
     int fused_into;            /* maxpool: index of the conv that computes it, or -1 */
+    int out_half;              /* this layer's activations are IEEE half (fp16 mode), out_ld counts halves */
+    size_t off_alpha, off_beta; /* fp16 mode: folded batch-norm, y = act(acc*alpha + beta) */
     char kname[80];
     /* region */
     float *d_anchors;
@@ -43,6 +45,7 @@ typedef struct y2_engine {
     int strict;
     int timing;
     int fusion, built_fusion;  /* conv+maxpool fusion enabled / state of the current plan */
+    int half, built_half;      /* fp16 storage requested (y2_set_half) / state of the current plan */
     int in_halo;               /* the NHWC copy of the input carries a one-pixel zero border */
     /* plan state */
     int built;

@@ -35,62 +35,7 @@
 // * scale, + bias, leaky as .1*x in double.
 //
 // This file is compiled with -ffp-contract=off: no mul+add below may fuse.
-#include "y2_common.hpp"
-#include <stdlib.h>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvK {
-    const float *x;
-    const float *w;
-    float *y;
-    const float *mean;
-    const double *rinv;
-    const float *scale;
-    const float *bias;
-    int H, W, Cin, ldx, Cout, ldy, K;
-    int npix;          // batch * H * W (output pixels == input pixels for the MFMA path)
-    int pool;          // 1: a 2x2 stride-2 maxpool is fused behind the activation (see pool_pixel)
-    int bn, act;
-    unsigned xbytes, wbytes;
-    int tiles_n;
-    int ntiles;        // tiles_m * tiles_n * ksplit work items; workgroups walk them with stride gridDim.x
-    int ksplit;        // >= 1: number of K ranges each output tile is cut into (split-K)
-    float *ws;         // split-K partial sums [ksplit][npix][Cout]
-    // direct kernel only
-    int size, stride, pad, out_h, out_w, batch;
-};
-
-__device__ __forceinline__ float epilogue(float v, bool bn, float mean, double rinv, float scale, float bias, int act)
-{
-    if (bn) {
-        float d = v - mean;                 // blas.c:122 numerator, fp32
-        v = (float)((double)d * rinv);      // divide by (sqrt(var)+1e-6f) evaluated in double
-        v = v * scale;                      // convolutional_layer.c:419
-    }
-    v = v + bias;                           // convolutional_layer.c:407
-    if (act == Y2H_ACT_LEAKY) v = (v > 0) ? v : (float)(.1 * (double)v);              // activations.h:41
-    else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));       // activations.h:35
-    else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);                             // activations.h:37
-    return v;
-}
-
-// Fused conv + 2x2/2 maxpool (maxpool_layer.c:79-114 with size 2, stride 2, pad 0).
-// The GEMM rows are enumerated in POOL-MAJOR order: row r = 4*q + t is pixel
-// (2*yo + t/2, 2*xo + t%2) of pooling window q = (n, yo, xo).  An MFMA accumulator lane holds
-// rows (reg&3) + 8*(reg>>2) + 4*half, i.e. registers 4g..4g+3 are the four pixels of ONE window,
-// so the pool is a max over four registers of the same lane -- no cross-lane traffic -- and the
-// full-resolution activation is never written.  Values are identical to conv followed by maxpool.
-__device__ __forceinline__ int pool_pixel(int r, int H, int W)
-{
-    const int q = r >> 2, t = r & 3;
-    const int Wp = W >> 1, HWp = (H >> 1) * Wp;
-    const int n = q / HWp, rem = q - n * HWp;
-    const int yo = rem / Wp, xo = rem - yo * Wp;
-    return (n * H + 2 * yo + (t >> 1)) * W + 2 * xo + (t & 1);
-}
+#include "y2_conv_shared.hpp"
 
 // ---------------------------------------------------------------------------
 // MFMA implicit GEMM
@@ -473,15 +418,21 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
                         const float v = epilogue(acc[j][4 * g + t], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
                         m = (v > m) ? v : m;
                     }
-                    if (co < a.Cout && r0 < a.npix) a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
+                    if (co < a.Cout && r0 < a.npix) {
+                        if (a.y_f16) ((_Float16 *)a.y)[(size_t)(r0 >> 2) * a.ldy + co] = (_Float16)m;
+                        else a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
+                    }
                 }
                 continue;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long p = prow + (r & 3) + 8 * (r >> 2);
-                if (co < a.Cout && p < a.npix)
-                    a.y[(size_t)p * a.ldy + co] = epilogue(acc[j][r], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+                if (co < a.Cout && p < a.npix) {
+                    const float v = epilogue(acc[j][r], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+                    if (a.y_f16) ((_Float16 *)a.y)[(size_t)p * a.ldy + co] = (_Float16)v;
+                    else a.y[(size_t)p * a.ldy + co] = v;
+                }
             }
         }
     };
@@ -502,6 +453,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
 // direct kernel (reference accumulation order; bit-identical to the CPU path)
 // weights in the reference's [n][c][kh][kw] layout
 // ---------------------------------------------------------------------------
+template <bool XH>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvK a)
 {
     const long total = (long)a.batch * a.out_h * a.out_w * a.Cout;
@@ -519,8 +471,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvK a)
                 for (int kw = 0; kw < a.size; ++kw) {
                     const int ix = ox * a.stride + kw - a.pad;
                     float xv = 0.f;
-                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                        xv = a.x[((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + c];
+                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                        const size_t xi = ((size_t)(n * a.H + iy) * a.W + ix) * a.ldx + c;
+                        xv = XH ? (float)((const _Float16 *)a.x)[xi] : a.x[xi];
+                    }
                     const float prod = wrow[(c * a.size + kh) * a.size + kw] * xv;
                     sum = sum + prod;
                 }
@@ -528,7 +482,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvK a)
         float mean = 0.f, scale = 1.f;
         double rinv = 1.0;
         if (a.bn) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
-        a.y[(size_t)op * a.ldy + co] = epilogue(sum, a.bn, mean, rinv, scale, a.bias[co], a.act);
+        const float v = epilogue(sum, a.bn, mean, rinv, scale, a.bias[co], a.act);
+        if (a.y_f16) ((_Float16 *)a.y)[(size_t)op * a.ldy + co] = (_Float16)v;
+        else a.y[(size_t)op * a.ldy + co] = v;
     }
 }
 
@@ -570,6 +526,7 @@ static Variant g_variants[] = {
 
 static bool mfma_ok(const y2h_conv *d)
 {
+    if (d->x_f16 || d->y_f16) return false;       // the fp32 matrix-core kernel reads and writes fp32 only
     if (!(d->size == 1 || d->size == 3)) return false;
     if (d->stride != 1 || d->pad != d->size / 2) return false;
     if (d->c % 16 != 0 || d->ldx % 4 != 0) return false;
@@ -659,13 +616,14 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
 extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)
 {
     int ksplit = 1;
-    if (d->x_halo || !mfma_ok(d) || !pick_variant(d, &ksplit) || ksplit <= 1) return 0;
+    if (d->x_halo || d->x_f16 || !mfma_ok(d) || !pick_variant(d, &ksplit) || ksplit <= 1) return 0;
     return (size_t)ksplit * d->batch * d->h * d->w * d->n * sizeof(float);
 }
 
 // first-layer kernel: 3 channels, 3x3/1 pad 1, <= 64 filters, input stored with a 1-pixel zero halo
 static bool first_ok(const y2h_conv *d)
 {
+    if (d->x_f16) return false;                   // reads the fp32 network input (writes fp32 or half)
     if (d->c != 3 || d->size != 3 || d->stride != 1 || d->pad != 1 || d->n > 64) return false;
     if (d->out_h != d->h || d->out_w != d->w || d->x_halo != 1) return false;
     const double xbytes = (double)d->batch * (d->h + 2) * (d->w + 2) * d->ldx * 4.0;
@@ -679,11 +637,19 @@ extern "C" int y2h_conv_first_layer_ok(const y2h_conv *d)
     return first_ok(&t) ? 1 : 0;
 }
 
-extern "C" int y2h_conv_uses_mfma(const y2h_conv *d) { return first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d)) ? 1 : 0; }
+extern "C" int y2h_conv_uses_mfma(const y2h_conv *d)
+{
+    if (d->x_f16) return y2_f16_conv_ok(d) ? 1 : 0;
+    return first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d)) ? 1 : 0;
+}
 
 extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
 {
     if (!strict && first_ok(d)) return d->n <= 32 ? "conv_first_mfma_f32_c3_n32" : "conv_first_mfma_f32_c3_n64";
+    if (d->x_f16) {
+        const char *nm = strict ? nullptr : y2_f16_conv_variant(d);
+        return nm ? nm : "conv_direct_f16";
+    }
     if (!strict && mfma_ok(d)) {
         Variant *v = pick_variant(d);
         if (v) return v->name;
@@ -707,10 +673,12 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     a.K = d->size * d->size * d->c;
     a.bn = d->batch_normalize; a.act = d->activation;
     a.size = d->size; a.stride = d->stride; a.pad = d->pad; a.out_h = d->out_h; a.out_w = d->out_w; a.batch = d->batch;
+    a.y_f16 = d->y_f16;
 
     if (d->fuse_maxpool2) {
         // only the matrix-core kernels pool in their epilogue, and 2x2/2 windows need even dims
-        if (strict || (d->h & 1) || (d->w & 1) || !(first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d))))
+        if (strict || (d->h & 1) || (d->w & 1) ||
+            !(first_ok(d) || y2_f16_conv_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d))))
             return Y2H_EINVAL;
         a.pool = 1;
     }
@@ -727,6 +695,7 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         return Y2H_OK;
     }
     if (d->x_halo != 0) return Y2H_EINVAL;       // only the first-layer kernel reads a haloed input
+    if (!strict && y2_f16_conv_ok(d)) return y2_f16_conv_launch(d, a, s);
     int ksplit = 1;
     Variant *v = (!strict && mfma_ok(d)) ? pick_variant(d, &ksplit) : nullptr;
     if (v) {
@@ -761,7 +730,8 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     if (!d->w_ref) return Y2H_EINVAL;     // direct kernel needs the reference-layout weights
     a.w = d->w_ref;
     const long total = (long)d->batch * d->out_h * d->out_w * d->n;
-    hipLaunchKernelGGL(conv_direct_kernel, dim3(y2h_grid(total, 256, 256 * 32)), dim3(256), 0, S(s), a);
+    if (d->x_f16) hipLaunchKernelGGL(conv_direct_kernel<true>, dim3(y2h_grid(total, 256, 256 * 32)), dim3(256), 0, S(s), a);
+    else hipLaunchKernelGGL(conv_direct_kernel<false>, dim3(y2h_grid(total, 256, 256 * 32)), dim3(256), 0, S(s), a);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }

@@ -1,0 +1,81 @@
+// Shared between the fp32 (y2_conv.hip) and fp16 (y2_conv_f16.hip) convolution kernels.
+#pragma once
+#include "y2_common.hpp"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct ConvK {
+    const float *x;    // fp16 kernels: const _Float16 *
+    const float *w;
+    float *y;          // y_f16: _Float16 *
+    const float *mean;
+    const double *rinv;
+    const float *scale;
+    const float *bias;
+    const float *alpha, *beta;   // fp16 path: y = act(acc * alpha[co] + beta[co])
+    int y_f16;         // 1: the output is stored as IEEE half
+    int H, W, Cin, ldx, Cout, ldy, K;
+    int npix;          // batch * H * W (output pixels == input pixels for the MFMA path)
+    int pool;          // 1: a 2x2 stride-2 maxpool is fused behind the activation (see pool_pixel)
+    int bn, act;
+    unsigned xbytes, wbytes;
+    int tiles_n;
+    int ntiles;        // tiles_m * tiles_n * ksplit work items; workgroups walk them with stride gridDim.x
+    int ksplit;        // >= 1: number of K ranges each output tile is cut into (split-K)
+    float *ws;         // split-K partial sums [ksplit][npix][Cout]
+    // direct kernel only
+    int size, stride, pad, out_h, out_w, batch;
+};
+
+// The reference's epilogue, step by step (blas.c:122, convolutional_layer.c:407-419, activations.h:35-41)
+__device__ __forceinline__ float epilogue(float v, bool bn, float mean, double rinv, float scale, float bias, int act)
+{
+    if (bn) {
+        float d = v - mean;                 // blas.c:122 numerator, fp32
+        v = (float)((double)d * rinv);      // divide by (sqrt(var)+1e-6f) evaluated in double
+        v = v * scale;                      // convolutional_layer.c:419
+    }
+    v = v + bias;                           // convolutional_layer.c:407
+    if (act == Y2H_ACT_LEAKY) v = (v > 0) ? v : (float)(.1 * (double)v);              // activations.h:41
+    else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));       // activations.h:35
+    else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);                             // activations.h:37
+    return v;
+}
+
+// fp16 path: BN folded into one fma on the fp32 accumulator (alpha = scale/(sqrt(var)+1e-6), beta = bias - mean*alpha),
+// fp32 activation.  There is no reference arithmetic to mirror here: the reference has no half path.
+__device__ __forceinline__ float epilogue_fast(float v, float alpha, float beta, int act)
+{
+    v = __builtin_fmaf(v, alpha, beta);
+    if (act == Y2H_ACT_LEAKY) v = (v > 0.f) ? v : 0.1f * v;
+    else if (act == Y2H_ACT_LOGISTIC) v = 1.f / (1.f + __expf(-v));
+    else if (act == Y2H_ACT_RELU) v = (v > 0.f) ? v : 0.f;
+    return v;
+}
+
+// Fused conv + 2x2/2 maxpool (maxpool_layer.c:79-114 with size 2, stride 2, pad 0).
+// The GEMM rows are enumerated in POOL-MAJOR order: row r = 4*q + t is pixel
+// (2*yo + t/2, 2*xo + t%2) of pooling window q = (n, yo, xo).  An MFMA accumulator lane holds
+// rows (reg&3) + 8*(reg>>2) + 4*half, i.e. registers 4g..4g+3 are the four pixels of ONE window,
+// so the pool is a max over four registers of the same lane -- no cross-lane traffic -- and the
+// full-resolution activation is never written.  Values are identical to conv followed by maxpool.
+__device__ __forceinline__ int pool_pixel(int r, int H, int W)
+{
+    const int q = r >> 2, t = r & 3;
+    const int Wp = W >> 1, HWp = (H >> 1) * Wp;
+    const int n = q / HWp, rem = q - n * HWp;
+    const int yo = rem / Wp, xo = rem - yo * Wp;
+    return (n * H + 2 * yo + (t >> 1)) * W + 2 * xo + (t & 1);
+}
+
+// fp16 side (y2_conv_f16.hip)
+bool y2_f16_conv_ok(const y2h_conv *d);
+const char *y2_f16_conv_variant(const y2h_conv *d);
+int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s);
+bool y2_f16_first_ok(const y2h_conv *d);
+int y2_f16_first_launch(const y2h_conv *d, ConvK &a, y2h_stream s);

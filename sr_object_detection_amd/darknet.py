@@ -166,6 +166,7 @@ def lib():
     L.cuda_set_device.argtypes = [C.c_int]
     L.y2_prepare.argtypes = [C.POINTER(CNetwork)]
     L.y2_set_strict.argtypes = [C.POINTER(CNetwork), C.c_int]
+    L.y2_set_half.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_fusion.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_timing.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_layer_times_ms.argtypes = [CNetwork, C.c_void_p, C.c_int]
@@ -346,6 +347,10 @@ class Network:
 
     def set_strict(self, on: bool) -> None:
         lib().y2_set_strict(C.byref(self.net), 1 if on else 0)
+
+    def set_half(self, on: bool) -> None:
+        """fp16 storage / fp32 accumulate (engine extension, include/sr_yolo2.h y2_set_half)."""
+        lib().y2_set_half(C.byref(self.net), 1 if on else 0)
 
     def set_fusion(self, on: bool) -> None:
         lib().y2_set_fusion(C.byref(self.net), 1 if on else 0)
