@@ -126,6 +126,9 @@ size_t y2h_conv_workspace_bytes(const y2h_conv *d);
 /* 1 when the shape fits the dedicated first-layer kernel (3 channels, 3x3/1 pad 1, <= 64
  * filters) provided the input is supplied with a halo (x_halo = 1) */
 int y2h_conv_first_layer_ok(const y2h_conv *d);
+/* same for the fp16 first-layer kernel, whose input is [batch][h+2][w+2][4] halves (x_f16 = 1, ldx = 4,
+ * layout of y2h_nchw_to_nhwc4_halo_f16) and whose weights stay the fp32 packed [n][27] */
+int y2h_conv_first_layer_f16_ok(const y2h_conv *d);
 /* strict != 0 forces the direct kernel, which accumulates in the reference's exact
  * order (ci, kh, kw ascending; product and sum rounded separately: gemm.c:74-88)
  * and is therefore bit-identical to the CPU path; needs w_ref. */
@@ -153,6 +156,8 @@ int y2h_reorg_f16(const void *x, int ldx, void *y, int ldy, int batch, int h, in
 int y2h_copy_channels_f16(const void *src, int ld_src, void *dst, int ld_dst, int c, long npix, y2h_stream s);
 int y2h_avgpool_f16(const void *x, int ldx, float *y, int batch, int h, int w, int c, y2h_stream s);  /* fp32 sum and result */
 int y2h_nhwc_f16_to_nchw(const void *src, int ld, float *dst, int n, int c, int h, int w, y2h_stream s);
+/* fp32 [n][3][h][w] -> interior of half [n][h+2][w+2][4] (channel 3 = 0; the border is not written) */
+int y2h_nchw_to_nhwc4_halo_f16(const float *src, void *dst, int n, int c, int h, int w, y2h_stream s);
 int y2h_f32_to_f16(const float *src, void *dst, long n, y2h_stream s);
 int y2h_f16_to_f32(const void *src, float *dst, long n, y2h_stream s);
 

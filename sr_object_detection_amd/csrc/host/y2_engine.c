@@ -174,18 +174,18 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     default: c->activation = -1; break;
     }
     c->x = x;
-    c->x_halo = (i == 0) ? e->in_halo : 0;
+    c->x_halo = (i == 0) ? (e->in_halo != 0) : 0;       /* in_halo 2: half [b][h+2][w+2][4] for the fp16 first-layer kernel */
     c->fuse_maxpool2 = d->fused_pool;
     c->ws = e->d_ws;
     c->ws_bytes = e->ws_bytes;
     c->y = d->out;
     c->y_f16 = d->out_half;
-    c->x_f16 = (i > 0) ? ld_of(&net->layers[i - 1])->out_half : 0;     /* the network input itself is fp32 */
+    c->x_f16 = (i > 0) ? ld_of(&net->layers[i - 1])->out_half : (e->in_halo == 2);
     if (e->arena) {
         c->w_packed = (const float *)(e->arena + d->off_w_packed);
         c->w_ref = d->has_w_ref ? (const float *)(e->arena + d->off_w_ref) : NULL;
         c->bias = (const float *)(e->arena + d->off_bias);
-        if (c->x_f16) {
+        if (c->x_f16 && i > 0) {
             c->alpha = (const float *)(e->arena + d->off_alpha);
             c->beta = (const float *)(e->arena + d->off_beta);
         }
@@ -200,7 +200,7 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
 static void input_view(const network *net, int i, const float **x, int *ldx)
 {
     const y2_engine *e = y2_engine_of(net);
-    if (i == 0) { *x = e->d_in_nhwc; *ldx = net->c; }
+    if (i == 0) { *x = e->d_in_nhwc; *ldx = (e->in_halo == 2) ? 4 : net->c; }
     else { const y2_ldev *p = ld_of(&net->layers[i - 1]); *x = p->out; *ldx = p->out_ld; }
 }
 
@@ -462,10 +462,13 @@ int y2_engine_build(network *net)
         c0.size = l0->size; c0.stride = l0->stride; c0.pad = l0->pad; c0.out_h = l0->out_h; c0.out_w = l0->out_w;
         c0.w_packed = (const float *)(uintptr_t)256;
         e->in_halo = y2h_conv_first_layer_ok(&c0);
+        /* fp16 mode: the first layer reads a half [b][h+2][w+2][4] copy of the input on the fp16 matrix cores */
+        if (e->half && ld_of(l0)->out_half && net->c <= 4 && y2h_conv_first_layer_f16_ok(&c0)) e->in_halo = 2;
     }
     HIPCALL(y2h_malloc((void **)&e->d_in_nchw, e->in_floats * sizeof(float)));
     {
         size_t nhwc = e->in_halo ? (size_t)net->batch * (net->h + 2) * (net->w + 2) * net->c : e->in_floats;
+        if (e->in_halo == 2) nhwc = (size_t)net->batch * (net->h + 2) * (net->w + 2) * 2;   /* 4 halves = 2 floats per pixel */
         HIPCALL(y2h_malloc((void **)&e->d_in_nhwc, nhwc * sizeof(float)));
         HIPCALL(y2h_memset(e->d_in_nhwc, 0, nhwc * sizeof(float), e->stream));     /* the halo stays zero */
     }
@@ -646,7 +649,9 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
     e = y2_engine_of(net);
     if (net->c <= 0 || net->h <= 0 || net->w <= 0) { y2_fail("network input must be an image (h,w,c > 0)"); return -1; }
     if (!d_input_nchw) d_input_nchw = e->d_in_nchw;     /* filled by y2_ingest_u8 */
-    if (e->in_halo)
+    if (e->in_halo == 2)
+        HIPCALL(y2h_nchw_to_nhwc4_halo_f16(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, e->stream));
+    else if (e->in_halo)
         HIPCALL(y2h_nchw_to_nhwc_halo(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));
     else
         HIPCALL(y2h_nchw_to_nhwc(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));

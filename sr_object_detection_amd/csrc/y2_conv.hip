@@ -637,9 +637,17 @@ extern "C" int y2h_conv_first_layer_ok(const y2h_conv *d)
     return first_ok(&t) ? 1 : 0;
 }
 
+extern "C" int y2h_conv_first_layer_f16_ok(const y2h_conv *d)
+{
+    y2h_conv t = *d;
+    t.x_halo = 1; t.x_f16 = 1; t.ldx = 4;
+    if (!t.x) t.x = (const float *)(uintptr_t)256;
+    return y2_f16_first_ok(&t) ? 1 : 0;
+}
+
 extern "C" int y2h_conv_uses_mfma(const y2h_conv *d)
 {
-    if (d->x_f16) return y2_f16_conv_ok(d) ? 1 : 0;
+    if (d->x_f16) return (y2_f16_first_ok(d) || y2_f16_conv_ok(d)) ? 1 : 0;
     return first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d)) ? 1 : 0;
 }
 
@@ -647,6 +655,7 @@ extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
 {
     if (!strict && first_ok(d)) return d->n <= 32 ? "conv_first_mfma_f32_c3_n32" : "conv_first_mfma_f32_c3_n64";
     if (d->x_f16) {
+        if (!strict && y2_f16_first_ok(d)) return d->n <= 32 ? "conv_first_mfma_f16_c3_n32" : "conv_first_mfma_f16_c3_n64";
         const char *nm = strict ? nullptr : y2_f16_conv_variant(d);
         return nm ? nm : "conv_direct_f16";
     }
@@ -678,10 +687,11 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     if (d->fuse_maxpool2) {
         // only the matrix-core kernels pool in their epilogue, and 2x2/2 windows need even dims
         if (strict || (d->h & 1) || (d->w & 1) ||
-            !(first_ok(d) || y2_f16_conv_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d))))
+            !(first_ok(d) || y2_f16_first_ok(d) || y2_f16_conv_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d))))
             return Y2H_EINVAL;
         a.pool = 1;
     }
+    if (!strict && y2_f16_first_ok(d)) return y2_f16_first_launch(d, a, s);
     if (!strict && first_ok(d)) {
         a.w = d->w_packed;
         a.npix = d->batch * d->h * d->w;

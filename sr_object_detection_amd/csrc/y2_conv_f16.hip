@@ -44,7 +44,6 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 
     const int sc = t % CH, sr = t / CH;
     unsigned a_off[PA], a_msk[PA], b_off[PB];
-    const int HW = a.H * a.W;
     const int nk = KS * KS * (a.Cin / BK);
     int tap = 0, c0 = 0;
     auto setup_tile = [&](int tile) {
@@ -52,27 +51,34 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
         c0 = 0;
         tap = 0;
         const int p0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+        // Row geometry with ONE coordinate decode per thread and tile: this thread's rows are RP apart, so the
+        // image coordinates of the following rows come from a carry update.  (With a matrix pipe this fast the
+        // per-row divisions and nine tap tests of the fp32 kernel's setup were ~10 % of a tile.)  Unit grid:
+        // pooling windows (row r = 4*window + corner) with the fused pool, pixels without.
+        const int Wu = a.pool ? a.W >> 1 : a.W, Hu = a.pool ? a.H >> 1 : a.H;
+        const int r0 = p0 + sr;
+        const int u0 = a.pool ? r0 >> 2 : r0, tc = r0 & 3;      // RP is a multiple of 4: the corner is the same for all q
+        int cn = u0 / (Hu * Wu);
+        int cy = (u0 - cn * Hu * Wu) / Wu, cx = u0 - cn * Hu * Wu - cy * Wu;
+        constexpr int USTEP_P = RP / 4, USTEP_N = RP;
 #pragma unroll
         for (int q = 0; q < PA; ++q) {
-            const int r = p0 + sr + q * RP;
-            const int p = a.pool ? pool_pixel(r, a.H, a.W) : r;
-            const int rem = p % HW;
-            const int py = rem / a.W, px = rem - py * a.W;
-            a_off[q] = ((unsigned)p * (unsigned)a.ldx + (unsigned)sc * 8u) * 2u;
+            const int r = r0 + q * RP;
+            const int py = a.pool ? 2 * cy + (tc >> 1) : cy, px = a.pool ? 2 * cx + (tc & 1) : cx;
+            a_off[q] = ((unsigned)((cn * a.H + py) * a.W + px) * (unsigned)a.ldx + (unsigned)sc * 8u) * 2u;
             unsigned m = 0;
             if (live && r < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
                 if (KS == 1) m = 1u;
                 else {
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) {
-                            const int yy = py + kh - 1, xx = px + kw - 1;
-                            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) m |= 1u << (kh * 3 + kw);
-                        }
+                    // bit kh*3+kw = tap inside the image: (column pattern) x (row pattern spread 3 bits apart), no carries
+                    const unsigned xm = (px > 0 ? 1u : 0u) | 2u | (px < a.W - 1 ? 4u : 0u);
+                    const unsigned ym = (py > 0 ? 1u : 0u) | 8u | (py < a.H - 1 ? 64u : 0u);
+                    m = xm * ym;
                 }
             }
             a_msk[q] = m;
+            cx += a.pool ? USTEP_P : USTEP_N;
+            while (cx >= Wu) { cx -= Wu; if (++cy >= Hu) { cy = 0; ++cn; } }
         }
 #pragma unroll
         for (int q = 0; q < PB; ++q) {
@@ -88,7 +94,11 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
         const long tl = (long)blockIdx.x + (long)i * gridDim.x;
         return tl < a.ntiles ? (int)tl : a.ntiles;
     };
-    int lti = 0;
+    // The staging side runs TWO slices ahead of the matrix side: the slice fetched during K-step k sits
+    // in registers for the whole step, is written to LDS at the start of step k+1 and multiplied in step
+    // k+2.  With a matrix pipe this fast one K-step is shorter than an L2 round trip, so a one-step
+    // distance (as in the fp32 kernel) would stall every step on the loads.
+    int lti = 0, stage_k = 0;          // staging cursor: tile index in this workgroup's sequence, slices loaded of it
     setup_tile(tile_at(0));
     auto load_slice = [&]() {
         int delta = 0;
@@ -110,6 +120,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
             rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
         }
         if (++tap == KS * KS) { tap = 0; c0 += BK; }
+        ++stage_k;
     };
     auto store_slice = [&](int buf) {
         _Float16 *As = smem_h + buf * BUF;
@@ -124,6 +135,8 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 
     load_slice();
     store_slice(0);
+    if (stage_k == nk) { setup_tile(tile_at(++lti)); stage_k = 0; }
+    load_slice();                      // slice 1 stays in registers
     __syncthreads();
 
     int cur = 0;
@@ -138,7 +151,9 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt == nk - 1) setup_tile(tile_at(++lti));      // the slice fetched now belongs to the next tile
+            // hop of the staging cursor to the workgroup's next tile: here, outside the K-step body, so that
+            // the body stays one scheduling region
+            if (stage_k == nk) { setup_tile(tile_at(++lti)); stage_k = 0; }
             // lane (row li, half lh) of a 32x32x16 operand holds k = 8*lh .. 8*lh+7 of its row
             const _Float16 *As = smem_h + cur * BUF + (wm * (BM / WM) + li) * LS + lh * 8;
             const _Float16 *Bs = smem_h + cur * BUF + BM * LS + (wn * (BN / WN) + li) * LS + lh * 8;
@@ -155,18 +170,22 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
             for (int kg = 0; kg < NG; ++kg) {
                 const int c = DB ? (kg & 1) : 0, n = DB ? (c ^ 1) : 0;
                 if (!DB) {
+                    if (!(a.dbg & 32) || kt == 0) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[0][i] = *(const f16x8 *)&As[i * 32 * LS + kg * 16];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bf[0][j] = *(const f16x8 *)&Bs[j * 32 * LS + kg * 16];
+                    }
                 } else if (kg + 1 < NG) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[n][i] = *(const f16x8 *)&As[i * 32 * LS + (kg + 1) * 16];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bf[n][j] = *(const f16x8 *)&Bs[j * 32 * LS + (kg + 1) * 16];
                 }
-                if (kg == 0) load_slice();
-                if (kg == NG - 1) store_slice(cur ^ 1);
+                // (a.dbg: tuning ablations -- 1 no LDS writes, 2 no global loads, 4 no output stores; results are garbage)
+                if (kg == 0 && !(a.dbg & 1)) store_slice(cur ^ 1);     // the slice loaded one step ago
+                if (kg == 1 && !(a.dbg & 2)) load_slice();             // two slices ahead
+                if (kg == 1 && (a.dbg & 2)) ++stage_k;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
                 if (DB) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (kg + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-                if (kg == 0) {
+                if (kg == 1) {
 #pragma unroll
                     for (int q = 0; q < PA + PB; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
-                if (kg == NG - 1) {
+                if (kg == 0) {
 #pragma unroll
                     for (int q = 0; q < PA + PB; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -195,16 +214,67 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
+            if (!(a.dbg & 16)) __syncthreads();
             cur ^= 1;
         }
 
         // epilogue: lane holds filter li of each 32x32 tile and 16 pixels
         _Float16 *yh = (_Float16 *)a.y;
+        if (a.vec_store) {
+            // Half outputs go out as 16-byte stores: a lane of the accumulator layout owns ONE filter of 16
+            // pixels, which would be sixteen 2-byte stores per 32x32 tile (measured: 38 % of the kernel).  Each
+            // wave transposes its tiles through 2.5 KB of the LDS buffer the K loop has just released (the other
+            // buffer already holds the next tile's first slice): 16 ds_write_b16, 2 ds_read_b128, 2 stores of
+            // 8 consecutive filters per lane.  LDS operations of one wave execute in order, so the wave-private
+            // scratch needs no barrier; the workgroup barrier below keeps the next K-step's staging writes out.
+            constexpr int ES = 40;                 // scratch row stride in halves (32 filters + 16 bytes)
+            static_assert(BUF >= WM * WN * 32 * ES, "epilogue scratch must fit in one staging buffer");
+            _Float16 *es = smem_h + (cur ^ 1) * BUF + wv * 32 * ES;
+            const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cb = n0 + wn * (BN / WN) + j * 32;       // first filter of this 32-wide tile
+                const int co = cb + li;
+                const bool cok = co < a.Cout;
+                const float alpha = cok ? a.alpha[co] : 0.f, beta = cok ? a.beta[co] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int pb = p0 + wm * (BM / WM) + i * 32;   // first GEMM row of this tile
+                    if (a.pool) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float m = epilogue_fast(acc[i][j][4 * g], alpha, beta, a.act);
+#pragma unroll
+                            for (int u = 1; u < 4; ++u) {
+                                const float v = epilogue_fast(acc[i][j][4 * g + u], alpha, beta, a.act);
+                                m = (v > m) ? v : m;
+                            }
+                            es[(2 * g + lh) * ES + li] = (_Float16)m;       // pooled row (pb + 8g + 4lh) / 4 - pb / 4
+                        }
+                        const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+                        const int prow = (pb >> 2) + rrow;
+                        if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout && !(a.dbg & 4))
+                            *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + li] = (_Float16)epilogue_fast(acc[i][j][r], alpha, beta, a.act);
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const f32x4 v = *(const f32x4 *)&es[(rrow + 16 * h2) * ES + rchunk];
+                            const int p = pb + rrow + 16 * h2;
+                            if (p < a.npix && cb + rchunk < a.Cout && !(a.dbg & 4)) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int co = n0 + wn * (BN / WN) + j * 32 + li;
-            const bool cok = co < a.Cout;
+            const bool cok = co < a.Cout && !(a.dbg & 4);
             const float alpha = cok ? a.alpha[co] : 0.f, beta = cok ? a.beta[co] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -344,6 +414,8 @@ int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     a.wbytes = (unsigned)((size_t)d->n * a.K * 2);
     a.tiles_n = (d->n + v->bn - 1) / v->bn;
     a.ksplit = 1;
+    if (const char *dbg = getenv("Y2_DBG")) a.dbg = atoi(dbg);
+    a.vec_store = d->y_f16 && d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !(a.dbg & 8);
     const long tiles_m = ((long)a.npix + v->bm - 1) / v->bm;
     int dev = 0;
     Y2H_CHECK(hipGetDevice(&dev));
@@ -359,5 +431,178 @@ int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     return Y2H_OK;
 }
 
-bool y2_f16_first_ok(const y2h_conv *) { return false; }
-int y2_f16_first_launch(const y2h_conv *, ConvK &, y2h_stream) { return Y2H_EINVAL; }
+// ---------------------------------------------------------------------------
+// First layer in fp16 mode (3 input channels, 3x3/1 pad 1, <= 64 filters).
+//
+// The layer is HBM bound (K = 27), so everything is about bytes and instruction count.  The network
+// input is converted once to half with FOUR channels per pixel (the fourth is zero) and a one-pixel
+// zero halo -- [batch][H+2][W+2][4], 8 bytes per pixel (y2h_nchw_to_nhwc4_halo_f16) -- so that a filter
+// tap of a pixel is one aligned 8-byte load and no tap needs a bounds test.  K is laid out as
+// k = tap*4 + ci (taps 9..11 and ci = 3 carry zero weights): 48 = three v_mfma_f32_32x32x16_f16 steps
+// per 32 pixels instead of the fourteen fp32 32x32x2 steps of conv_first_kernel.  Lane (pixel r, half h)
+// of step s holds taps 4s+2h and 4s+2h+1: five 8-byte loads per lane and tile.  The filter fragments
+// (converted from the fp32 packed weights) and the folded batch-norm constants live in registers for
+// the whole kernel; no LDS.
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_first_f16_kernel(ConvK a)
+{
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long nwaves = (long)gridDim.x * 4;
+    const long ntiles = ((long)a.npix + 31) / 32;
+    const int W2 = a.W + 2, H2 = a.H + 2, HW = a.H * a.W;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+
+    // taps of this lane: step s -> taps 4s+2lh, 4s+2lh+1 (>= 9: none)
+    unsigned delta[3][2];
+    bool live[3][2];
+    f16x8 bw[NT][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tap = 4 * s + 2 * lh + u;
+            live[s][u] = tap < 9;
+            const int tt = live[s][u] ? tap : 0;
+            const int kh = tt / 3, kw = tt - kh * 3;
+            delta[s][u] = (unsigned)((kh * W2 + kw) * 8);                 // 4 halves per pixel
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = j * 32 + li;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    float w = 0.f;
+                    if (live[s][u] && ci < 3 && co < a.Cout) w = a.w[(size_t)co * 27 + tap * 3 + ci];
+                    bw[j][s][u * 4 + ci] = (_Float16)w;
+                }
+            }
+        }
+    float alpha[NT], beta[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = j * 32 + li;
+        alpha[j] = 0.f; beta[j] = 0.f;
+        if (co < a.Cout) {
+            double al = 1.0, be = a.bias[co];
+            if (a.bn) { al = (double)a.scale[co] * a.rinv[co]; be = (double)a.bias[co] - (double)a.mean[co] * al; }
+            alpha[j] = (float)al; beta[j] = (float)be;
+        }
+    }
+
+    // Each wave owns a CONTIGUOUS run of tiles, so the image coordinates of a lane's pixel advance by a
+    // constant step from tile to tile (carry logic instead of five integer divisions per tile, which
+    // would make this HBM-bound kernel VALU bound).  Unit grid: pooling windows (H/2 x W/2, 8 per tile,
+    // lane = window li/4, corner li%4) with the fused pool, pixels (H x W, 32 per tile) without.
+    const long chunk = (ntiles + nwaves - 1) / nwaves;
+    const long t_begin = wave * chunk, t_end = (t_begin + chunk < ntiles) ? t_begin + chunk : ntiles;
+    const int Wu = a.pool ? a.W >> 1 : a.W, Hu = a.pool ? a.H >> 1 : a.H;
+    const int ustep = a.pool ? 8 : 32;
+    const long nunits = (long)a.batch * Hu * Wu;
+    long unit = t_begin * ustep + (a.pool ? (li >> 2) : li);      // unit of the NEXT tile to load
+    int cn, cy, cx;
+    {
+        const long uu = unit < nunits ? unit : 0;
+        cn = (int)(uu / ((long)Hu * Wu));
+        const int rem = (int)(uu - (long)cn * Hu * Wu);
+        cy = rem / Wu; cx = rem - cy * Wu;
+    }
+    auto load_tile = [&](u32x2 (&av)[3][2]) {
+        const int py = a.pool ? 2 * cy + ((li >> 1) & 1) : cy, px = a.pool ? 2 * cx + (li & 1) : cx;
+        const unsigned base = (unit < nunits) ? ((unsigned)(cn * H2 + py) * (unsigned)W2 + (unsigned)px) * 8u : a.xbytes;
+        unit += ustep;
+        cx += ustep;
+        while (cx >= Wu) { cx -= Wu; if (++cy >= Hu) { cy = 0; ++cn; } }
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // dead taps read out of range: zeros, no traffic (their weights are zero as well)
+                const unsigned off = (live[s][u] && base != a.xbytes) ? base + delta[s][u] : a.xbytes;
+                av[s][u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
+            }
+    };
+    auto compute_tile = [&](long tile, const u32x2 (&av)[3][2]) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            u32x4 q;
+            q[0] = av[s][0][0]; q[1] = av[s][0][1]; q[2] = av[s][1][0]; q[3] = av[s][1][1];
+            const f16x8 af = __builtin_bit_cast(f16x8, q);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bw[j][s], acc[j], 0, 0, 0);
+        }
+        const long prow = tile * 32 + 4 * lh;
+        _Float16 *yh = (_Float16 *)a.y;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = j * 32 + li;
+            if (a.pool) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const long r0 = prow + 8 * g;
+                    float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], a.act);
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) {
+                        const float v = epilogue_fast(acc[j][4 * g + t], alpha[j], beta[j], a.act);
+                        m = (v > m) ? v : m;
+                    }
+                    if (co < a.Cout && r0 < a.npix) {
+                        const size_t o = (size_t)(r0 >> 2) * a.ldy + co;
+                        if (a.y_f16) yh[o] = (_Float16)m; else a.y[o] = m;
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long p = prow + (r & 3) + 8 * (r >> 2);
+                if (co < a.Cout && p < a.npix) {
+                    const float v = epilogue_fast(acc[j][r], alpha[j], beta[j], a.act);
+                    const size_t o = (size_t)p * a.ldy + co;
+                    if (a.y_f16) yh[o] = (_Float16)v; else a.y[o] = v;
+                }
+            }
+        }
+    };
+
+    u32x2 a0[3][2], a1[3][2];
+    long tile = t_begin;
+    if (tile < t_end) load_tile(a0);
+    for (; tile < t_end; tile += 2) {
+        if (tile + 1 < t_end) load_tile(a1);
+        compute_tile(tile, a0);
+        if (tile + 2 < t_end) load_tile(a0);
+        if (tile + 1 < t_end) compute_tile(tile + 1, a1);
+    }
+}
+
+// x is the half NHWC4 haloed input (x_f16 = 1, x_halo = 1, ldx = 4), weights are the fp32 packed [n][27]
+bool y2_f16_first_ok(const y2h_conv *d)
+{
+    if (!d->x_f16 || d->x_halo != 1 || d->ldx != 4) return false;
+    if (d->c != 3 || d->size != 3 || d->stride != 1 || d->pad != 1 || d->n > 64) return false;
+    if (d->out_h != d->h || d->out_w != d->w) return false;
+    const double xbytes = (double)d->batch * (d->h + 2) * (d->w + 2) * 8.0;
+    return xbytes < 4294967000.0 && d->w_packed != nullptr && ((uintptr_t)d->x % 8) == 0;
+}
+
+int y2_f16_first_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
+{
+    a.w = d->w_packed;
+    a.npix = d->batch * d->h * d->w;
+    a.xbytes = (unsigned)((size_t)d->batch * (d->h + 2) * (d->w + 2) * 8);
+    const long ntiles = ((long)a.npix + 31) / 32;
+    long blocks = (ntiles + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;          // tiles are grid-strided
+    if (d->n <= 32) hipLaunchKernelGGL(conv_first_f16_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+    else hipLaunchKernelGGL(conv_first_f16_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

@@ -19,6 +19,8 @@ struct ConvK {
     const float *bias;
     const float *alpha, *beta;   // fp16 path: y = act(acc * alpha[co] + beta[co])
     int y_f16;         // 1: the output is stored as IEEE half
+    int vec_store;     // fp16 kernels: half outputs leave as 16-byte stores (ldy, y and Cout aligned to 8 halves)
+    int dbg;           // ablation switches for tuning runs (env Y2_DBG; 0 in normal use): see y2_conv_f16.hip
     int H, W, Cin, ldx, Cout, ldy, K;
     int npix;          // batch * H * W (output pixels == input pixels for the MFMA path)
     int pool;          // 1: a 2x2 stride-2 maxpool is fused behind the activation (see pool_pixel)
@@ -52,7 +54,7 @@ __device__ __forceinline__ float epilogue(float v, bool bn, float mean, double r
 __device__ __forceinline__ float epilogue_fast(float v, float alpha, float beta, int act)
 {
     v = __builtin_fmaf(v, alpha, beta);
-    if (act == Y2H_ACT_LEAKY) v = (v > 0.f) ? v : 0.1f * v;
+    if (act == Y2H_ACT_LEAKY) v = __builtin_fmaxf(v, 0.1f * v);       // slope < 1: max(v, .1v) is the leaky select
     else if (act == Y2H_ACT_LOGISTIC) v = 1.f / (1.f + __expf(-v));
     else if (act == Y2H_ACT_RELU) v = (v > 0.f) ? v : 0.f;
     return v;

@@ -210,6 +210,35 @@ extern "C" int y2h_nhwc_f16_to_nchw(const void *src, int ld, float *dst, int n, 
     return Y2H_OK;
 }
 
+// network input for the fp16 first-layer kernel: fp32 NCHW (<= 4 planes) -> half [n][h+2][w+2][4], interior only;
+// one thread per pixel reads its planes (coalesced along x) and writes one 8-byte pixel
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_halo_f16_kernel(const float *__restrict__ src, _Float16 *__restrict__ dst,
+                                                                     int c, int h, int w, long total)
+{
+    const long hw = (long)h * w;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int x = (int)(idx % w);
+        const int y = (int)((idx / w) % h);
+        const long n = idx / hw;
+        const float *s = src + n * c * hw + (long)y * w + x;
+        h4 px;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) px[k] = (k < c) ? (_Float16)s[k * hw] : (_Float16)0.f;
+        *(h4 *)&dst[((n * (h + 2) + (y + 1)) * (long)(w + 2) + (x + 1)) * 4] = px;
+    }
+}
+
+extern "C" int y2h_nchw_to_nhwc4_halo_f16(const float *src, void *dst, int n, int c, int h, int w, y2h_stream s)
+{
+    if (!src || !dst || n <= 0 || c <= 0 || c > 4 || h <= 0 || w <= 0 || ((uintptr_t)dst % 8) != 0) return Y2H_EINVAL;
+    const long total = (long)n * h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc4_halo_f16_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), src, (_Float16 *)dst,
+                       c, h, w, total);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
 // array conversions (weights are converted on the host; these serve the kernel-level tests)
 __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float *__restrict__ src, _Float16 *__restrict__ dst, long n)
 {
