@@ -72,7 +72,6 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     unsigned a_off[PA];      // byte offset of the pixel's channel 0 (+ this thread's chunk)
     unsigned a_msk[PA];      // validity of the KS*KS taps
     unsigned b_off[PB];
-    const int HW = a.H * a.W;
     // row metadata of the tile the STAGING side is working on (tiles past the end: everything masked)
     // A work item ("virtual tile") v is K-split ks = v % ksplit of output tile v / ksplit: it covers the
     // slices [ks*nk/ksplit, (ks+1)*nk/ksplit) of the K loop (split-K, for grids too small to fill 256 CUs).
@@ -85,27 +84,34 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     c0 = (kb / (KS * KS)) * BK;
     tap = kb % (KS * KS);
     const int p0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+    // One coordinate decode per thread and tile: this thread's rows are RP apart, so the image coordinates
+    // of the following rows come from a carry update (unit grid = pooling windows, row r = 4*window + corner,
+    // with the fused pool; pixels without), and the nine tap tests collapse into one product of a column and a
+    // row pattern.  The setup runs on the VALU while the matrix pipe waits, so its length matters on short-K layers.
+    const int Wu = a.pool ? a.W >> 1 : a.W, Hu = a.pool ? a.H >> 1 : a.H;
+    const int r0 = p0 + sr;
+    const int u0 = a.pool ? r0 >> 2 : r0, tc = r0 & 3;        // RP % 4 == 0: the corner is the same for every q
+    int cn = u0 / (Hu * Wu);
+    int cy = (u0 - cn * Hu * Wu) / Wu, cx = u0 - cn * Hu * Wu - cy * Wu;
+    static_assert(RP % 4 == 0, "rows of one thread must keep their pooling-window corner");
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
-        const int r = p0 + sr + q * RP;                       // GEMM row
-        const int p = a.pool ? pool_pixel(r, a.H, a.W) : r;   // linear NHWC pixel it stands for
-        const int rem = p % HW;
-        const int py = rem / a.W, px = rem - py * a.W;
-        a_off[q] = ((unsigned)p * (unsigned)a.ldx + (unsigned)sc * 4u) * 4u;
+        const int r = r0 + q * RP;                            // GEMM row
+        const int py = a.pool ? 2 * cy + (tc >> 1) : cy, px = a.pool ? 2 * cx + (tc & 1) : cx;
+        a_off[q] = ((unsigned)((cn * a.H + py) * a.W + px) * (unsigned)a.ldx + (unsigned)sc * 4u) * 4u;
         unsigned m = 0;
         if (live && r < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
             if (KS == 1) m = 1u;
             else {
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int yy = py + kh - 1, xx = px + kw - 1;
-                        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) m |= 1u << (kh * 3 + kw);
-                    }
+                // bit kh*3+kw = tap inside the image: (column pattern) x (row pattern spread 3 bits apart), no carries
+                const unsigned xm = (px > 0 ? 1u : 0u) | 2u | (px < a.W - 1 ? 4u : 0u);
+                const unsigned ym = (py > 0 ? 1u : 0u) | 8u | (py < a.H - 1 ? 64u : 0u);
+                m = xm * ym;
             }
         }
         a_msk[q] = m;
+        cx += a.pool ? RP / 4 : RP;
+        while (cx >= Wu) { cx -= Wu; if (++cy >= Hu) { cy = 0; ++cn; } }
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
     const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
     const long nwaves = (long)gridDim.x * 4;
     const long ntiles = ((long)a.npix + 31) / 32;
-    const int W2 = a.W + 2, H2 = a.H + 2, HW = a.H * a.W;
+    const int W2 = a.W + 2, H2 = a.H + 2;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
 
     float bw[NT][14];
@@ -381,17 +387,33 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
         }
     }
 
-    auto load_tile = [&](long tile, float (&av)[14]) {
-        long p = tile * 32 + li;
-        if (p >= a.npix) p = a.npix - 1;
-        if (a.pool) p = pool_pixel((int)p, a.H, a.W);
-        const int n = (int)(p / HW);
-        const int rem = (int)(p - (long)n * HW);
-        const int py = rem / a.W, px = rem - py * a.W;
-        const unsigned base = ((unsigned)(n * H2 + py) * (unsigned)W2 + (unsigned)px) * (unsigned)a.ldx * 4u;
+    // Each wave owns a CONTIGUOUS run of tiles, so a lane's image coordinates advance by a constant step from
+    // tile to tile: a carry update instead of five integer divisions per tile (which made this HBM-bound kernel
+    // VALU bound).  Unit grid: pooling windows (8 per tile, lane = window li/4, corner li%4) with the fused
+    // pool, pixels (32 per tile) without.
+    const long chunk = (ntiles + nwaves - 1) / nwaves;
+    const long t_begin = wave * chunk, t_end = (t_begin + chunk < ntiles) ? t_begin + chunk : ntiles;
+    const int Wu = a.pool ? a.W >> 1 : a.W, Hu = a.pool ? a.H >> 1 : a.H;
+    const int ustep = a.pool ? 8 : 32;
+    const long nunits = (long)a.batch * Hu * Wu;
+    long unit = t_begin * ustep + (a.pool ? (li >> 2) : li);      // unit of the NEXT tile to load
+    int cn, cy, cx;
+    {
+        const long uu = unit < nunits ? unit : 0;
+        cn = (int)(uu / ((long)Hu * Wu));
+        const int rem = (int)(uu - (long)cn * Hu * Wu);
+        cy = rem / Wu; cx = rem - cy * Wu;
+    }
+    auto load_tile = [&](float (&av)[14]) {
+        const int py = a.pool ? 2 * cy + ((li >> 1) & 1) : cy, px = a.pool ? 2 * cx + (li & 1) : cx;
+        // rows past the end read out of range: zeros, no traffic (their results are never stored)
+        const unsigned base = (unit < nunits) ? ((unsigned)(cn * H2 + py) * (unsigned)W2 + (unsigned)px) * (unsigned)a.ldx * 4u : a.xbytes;
+        unit += ustep;
+        cx += ustep;
+        while (cx >= Wu) { cx -= Wu; if (++cy >= Hu) { cy = 0; ++cn; } }
 #pragma unroll
         for (int t = 0; t < 14; ++t)
-            av[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, base + delta[t], 0, 0));
+            av[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, base == a.xbytes ? base : base + delta[t], 0, 0));
     };
     auto compute_tile = [&](long tile, const float (&av)[14]) {
         f32x16 acc[NT];
@@ -438,14 +460,13 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
     };
 
     float a0[14], a1[14];
-    long tile = wave;
-    if (tile < ntiles) load_tile(tile, a0);
-    for (; tile < ntiles; tile += 2 * nwaves) {
-        const long t1 = tile + nwaves, t2 = tile + 2 * nwaves;
-        if (t1 < ntiles) load_tile(t1, a1);
+    long tile = t_begin;
+    if (tile < t_end) load_tile(a0);
+    for (; tile < t_end; tile += 2) {
+        if (tile + 1 < t_end) load_tile(a1);
         compute_tile(tile, a0);
-        if (t2 < ntiles) load_tile(t2, a0);
-        if (t1 < ntiles) compute_tile(t1, a1);
+        if (tile + 2 < t_end) load_tile(a0);
+        if (tile + 1 < t_end) compute_tile(tile + 1, a1);
     }
 }
 
