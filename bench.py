@@ -269,7 +269,8 @@ def main():
                         avg_launch_gflop=round(per_kernel_flops[dom] / per_kernel_launches[dom] / 1e9, 3))
         conv_ms = sum(per_kernel_ms.values()) / max(args.steps, 1)
         cfg_b1 = write_cfg(tmp, name, size, 1, "net_b1.cfg")
-        cpu = cpu_baseline(cfg_b1, wts, size, args.cpu_iters, tmp)
+        # the CPU leg is timed at N=1 only (rank 0 would otherwise hold the other ranks at the final barrier)
+        cpu = cpu_baseline(cfg_b1, wts, size, args.cpu_iters, tmp) if world == 1 else None
         line = {
             "metric": "images/sec YOLOv2 608x608 fp32" if (size == 608 and not half) else
                       "images/sec %s %dx%d %s" % (name, size, size, "fp16" if half else "fp32"),

@@ -280,6 +280,10 @@ int y2_detect(network net, float *input, float thresh, float nms, int img_w, int
  * Same result as ipl_to_image + rgbgr_image + resize_image/letterbox_image + the float path
  * (yolo_v2_class.hpp:94-141, yolo_v2_class.cpp:173-249).  y2_ingest_u8 stops after filling the
  * network's device input (follow with y2_forward_device(net, NULL)). */
+/* Float CHW frame of any size (batch-1 networks): its first net.c planes go up and are resized on the device
+ * straight into the network input -- resize_image + the input copy of network_predict (detector.c:567-573)
+ * without a host round trip.  Follow with y2_forward_device(net, NULL) / y2_network_predict_device(net, NULL). */
+int y2_ingest_image(network net, image im);
 int y2_ingest_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox);
 int y2_detect_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox,
                  float thresh, float nms, int img_w, int img_h, y2_det *dets, int *counts, int max_per_image);

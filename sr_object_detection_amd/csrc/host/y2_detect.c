@@ -197,21 +197,39 @@ image make_image(int w, int h, int c)        /* image.c:1436 */
 }
 void free_image(image m) { free(m.data); }
 
+/* scratch of the image-in/image-out helpers (resize_image, letterbox_image): one stream and three grow-only
+ * device buffers per device, so that a per-frame caller pays no hipMalloc/hipFree (not thread-safe, like the
+ * reference's own static buffers) */
+static struct { float *d_src, *d_tmp, *d_dst; size_t src_cap, tmp_cap, dst_cap; y2h_stream stream; int device; } g_img = {0, 0, 0, 0, 0, 0, 0, -1};
+
+static int img_scratch(const char *who, size_t ns, size_t nt, size_t nd)
+{
+    int dev = 0;
+    if (y2h_device_count() <= 0) { y2_fail("%s: no HIP device visible and this library has no CPU path", who); return -1; }
+    if (gpu_index >= 0) y2h_set_device(gpu_index);
+    HIPCALL_I(y2h_get_device(&dev));
+    if (g_img.device != dev) {
+        g_img.d_src = g_img.d_tmp = g_img.d_dst = NULL;
+        g_img.src_cap = g_img.tmp_cap = g_img.dst_cap = 0; g_img.stream = NULL;      /* per-device scratch */
+        g_img.device = dev;
+    }
+    if (!g_img.stream) HIPCALL_I(y2h_stream_create(&g_img.stream));
+    if (ns > g_img.src_cap) { y2h_free(g_img.d_src); g_img.d_src = NULL; g_img.src_cap = 0; HIPCALL_I(y2h_malloc((void **)&g_img.d_src, ns * 4)); g_img.src_cap = ns; }
+    if (nt > g_img.tmp_cap) { y2h_free(g_img.d_tmp); g_img.d_tmp = NULL; g_img.tmp_cap = 0; HIPCALL_I(y2h_malloc((void **)&g_img.d_tmp, nt * 4)); g_img.tmp_cap = nt; }
+    if (nd > g_img.dst_cap) { y2h_free(g_img.d_dst); g_img.d_dst = NULL; g_img.dst_cap = 0; HIPCALL_I(y2h_malloc((void **)&g_img.d_dst, nd * 4)); g_img.dst_cap = nd; }
+    return 0;
+}
+
 image resize_image(image im, int w, int h)   /* image.c:1950-1992, on the device */
 {
     image out = make_image(w, h, im.c);
-    float *d_src = NULL, *d_tmp = NULL, *d_dst = NULL;
-    y2h_stream s = NULL;
     size_t ns = (size_t)im.w * im.h * im.c, nt = (size_t)w * im.h * im.c, nd = (size_t)w * h * im.c;
-    if (y2h_device_count() <= 0) { y2_fail("resize_image: no HIP device visible and this library has no CPU path"); return out; }
-    if (gpu_index >= 0) y2h_set_device(gpu_index);
-    if (y2h_stream_create(&s) || y2h_malloc((void **)&d_src, ns * 4) || y2h_malloc((void **)&d_tmp, nt * 4) ||
-        y2h_malloc((void **)&d_dst, nd * 4) || y2h_memcpy_h2d(d_src, im.data, ns * 4, s) ||
-        y2h_resize_chw(d_src, im.c, im.h, im.w, d_tmp, d_dst, h, w, s) || y2h_memcpy_d2h(out.data, d_dst, nd * 4, s) ||
-        y2h_stream_sync(s))
+    if (!im.data || ns == 0 || nd == 0) { y2_fail("resize_image: empty image"); return out; }
+    if (img_scratch("resize_image", ns, nt, nd) != 0) return out;
+    if (y2h_memcpy_h2d(g_img.d_src, im.data, ns * 4, g_img.stream) ||
+        y2h_resize_chw(g_img.d_src, im.c, im.h, im.w, g_img.d_tmp, g_img.d_dst, h, w, g_img.stream) ||
+        y2h_memcpy_d2h(out.data, g_img.d_dst, nd * 4, g_img.stream) || y2h_stream_sync(g_img.stream))
         y2_fail("resize_image: %s", y2h_last_error());
-    y2h_free(d_src); y2h_free(d_tmp); y2h_free(d_dst);
-    y2h_stream_destroy(s);
     return out;
 }
 
@@ -298,18 +316,17 @@ int y2_detect(network net, float *input, float thresh, float nms, int img_w, int
  * embedded centred; letterbox_image fills the box with .5 first, _into keeps what `boxed` holds. */
 static int letterbox_device(image im, int w, int h, image boxed, int fill)
 {
-    float *d_src = NULL, *d_tmp = NULL, *d_dst = NULL;
-    y2h_stream s = NULL;
+    float *d_src, *d_tmp, *d_dst;
+    y2h_stream s;
     int nw, nh, rc;
     size_t ns = (size_t)im.w * im.h * im.c, nd = (size_t)w * h * im.c, nt;
-    if (y2h_device_count() <= 0) { y2_fail("letterbox_image: no HIP device visible and this library has no CPU path"); return -1; }
     if (!im.data || !boxed.data || im.w <= 0 || im.h <= 0 || w <= 0 || h <= 0) { y2_fail("letterbox_image: empty image"); return -1; }
     y2h_letterbox_dims(im.w, im.h, w, h, &nw, &nh);
     if (nw <= 0 || nh <= 0) { y2_fail("letterbox_image: degenerate size %d x %d", nw, nh); return -1; }
     nt = (size_t)im.c * im.h * nw + (size_t)im.c * nh * nw;
-    if (gpu_index >= 0) y2h_set_device(gpu_index);
-    rc = y2h_stream_create(&s) || y2h_malloc((void **)&d_src, ns * 4) || y2h_malloc((void **)&d_tmp, nt * 4) ||
-         y2h_malloc((void **)&d_dst, nd * 4) || y2h_memcpy_h2d(d_src, im.data, ns * 4, s);
+    if (img_scratch("letterbox_image", ns, nt, nd) != 0) return -1;
+    d_src = g_img.d_src; d_tmp = g_img.d_tmp; d_dst = g_img.d_dst; s = g_img.stream;
+    rc = y2h_memcpy_h2d(d_src, im.data, ns * 4, s);
     if (!rc) {
         if (fill) rc = y2h_letterbox_chw(d_src, im.c, im.h, im.w, d_tmp, d_dst, h, w, s);
         else {
@@ -320,8 +337,6 @@ static int letterbox_device(image im, int w, int h, image boxed, int fill)
     }
     rc = rc || y2h_memcpy_d2h(boxed.data, d_dst, nd * 4, s) || y2h_stream_sync(s);
     if (rc) y2_fail("letterbox_image: %s", y2h_last_error());
-    y2h_free(d_src); y2h_free(d_tmp); y2h_free(d_dst);
-    y2h_stream_destroy(s);
     return rc ? -1 : 0;
 }
 
@@ -381,6 +396,32 @@ int y2_ingest_u8(network net, const unsigned char *frames, int h, int w, int c, 
     return 0;
 }
 
+/* A float CHW frame of any size (the `image` the reference's callers hold): its first net.c planes are uploaded
+ * and resized (image.c:1950) straight into the network's device input -- what resize_image + the input copy of
+ * network_predict do in the reference (detector.c:567-573), without the host round trip or any allocation. */
+int y2_ingest_image(network net, image im)
+{
+    y2_engine *e;
+    size_t plane = (size_t)im.w * im.h, ntmp;
+    if (!im.data || im.w <= 0 || im.h <= 0) { y2_fail("y2_ingest_image: empty image"); return -1; }
+    if (im.c < net.c) { y2_fail("y2_ingest_image: the image has %d planes, the network reads %d", im.c, net.c); return -1; }
+    if (net.batch != 1) { y2_fail("y2_ingest_image: set_batch_network(&net, 1) first"); return -1; }
+    if (y2_prepare(&net) != 0) return -1;
+    e = y2_engine_of(&net);
+    HIPCALL_I(y2h_set_device(e->device));
+    if (im.w == net.w && im.h == net.h) {
+        HIPCALL_I(y2h_memcpy_h2d(e->d_in_nchw, im.data, plane * net.c * sizeof(float), e->stream));
+        return 0;
+    }
+    ntmp = (size_t)net.c * im.h * net.w;
+    if (grow((void **)&e->d_planes, &e->planes_cap, plane * net.c * 4) || grow((void **)&e->d_rtmp, &e->rtmp_cap, ntmp * 4)) {
+        y2_fail("y2_ingest_image: %s", y2h_last_error()); return -1;
+    }
+    HIPCALL_I(y2h_memcpy_h2d(e->d_planes, im.data, plane * net.c * sizeof(float), e->stream));
+    HIPCALL_I(y2h_resize_chw(e->d_planes, net.c, im.h, im.w, e->d_rtmp, e->d_in_nchw, net.h, net.w, e->stream));
+    return 0;
+}
+
 int y2_detect_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox,
                  float thresh, float nms, int img_w, int img_h, y2_det *dets, int *counts, int max_per_image)
 {
@@ -398,16 +439,17 @@ void test_detector_img(char **names, image **alphabet, network net, image im, fl
                        object *RecObects, int *objectNumPerFrame)
 {
     const float nms = 0.1f;
-    image sized = resize_image(im, net.w, net.h);
     layer l = net.layers[net.n - 1];
     int total = l.w * l.h * l.n, n, i;
     y2_det *dets;
     int count = 0;
     (void)alphabet;
-    if (y2_failed()) { free_image(sized); return; }
-    if (net.batch != 1) { free_image(sized); y2_fail("test_detector_img: set_batch_network(&net, 1) first"); return; }
+    if (net.batch != 1) { y2_fail("test_detector_img: set_batch_network(&net, 1) first"); return; }
+    /* resize_image + network_predict's input copy, fused on the device (planes are resized independently, so
+     * resizing only the planes the network reads gives the same input as the reference's 4-plane resize) */
+    if (y2_ingest_image(net, im) != 0) return;
     dets = calloc(total > 0 ? total : 1, sizeof(y2_det));
-    if (y2_detect(net, sized.data, thresh, nms, 1, 1, dets, &count, total) != 0) { free(dets); free_image(sized); return; }
+    if (y2_forward_device(net, NULL) != 0 || y2_detect_resident(net, thresh, nms, 1, 1, dets, &count, total) != 0) { free(dets); return; }
     n = count < total ? count : total;
     for (i = 0; i < n; ++i) {
         object *o = &RecObects[*objectNumPerFrame];
@@ -425,5 +467,4 @@ void test_detector_img(char **names, image **alphabet, network net, image im, fl
         (*objectNumPerFrame)++;
     }
     free(dets);
-    free_image(sized);
 }

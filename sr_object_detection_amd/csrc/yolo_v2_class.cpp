@@ -141,16 +141,15 @@ std::vector<bbox_t> Detector::detect(image_t img, float thresh, bool use_mean)
     network &net = st.net;
     if (!img.data) throw std::runtime_error("Image is empty");
     image im; im.w = img.w; im.h = img.h; im.c = img.c; im.data = img.data;
-    image sized = im;
-    bool own = false;
-    if (net.w != im.w || net.h != im.h) { sized = resize_image(im, net.w, net.h); own = true; }
+    // cpp:195-200 resize_image when the sizes differ, then the input copy of network_predict: one upload and
+    // a device-side resize straight into the network input
+    if (y2_ingest_image(net, im) != 0) throw std::runtime_error(y2_last_error());
     const layer &last = net.layers[net.n - 1];
     const int total = last.w * last.h * last.n;
     std::vector<bbox_t> out;
     if (!use_mean) {
         int count = 0;
-        const int rc = y2_detect(net, sized.data, thresh, nms, 1, 1, st.dets.data(), &count, total);
-        if (own) ::free_image(sized);
+        const int rc = y2_forward_device(net, NULL) || y2_detect_resident(net, thresh, nms, 1, 1, st.dets.data(), &count, total);
         if (rc != 0) throw std::runtime_error(y2_last_error());
         for (int i = 0; i < std::min(count, total); ++i) {
             const y2_det &d = st.dets[i];
@@ -158,8 +157,7 @@ std::vector<bbox_t> Detector::detect(image_t img, float thresh, bool use_mean)
         }
         return out;
     }
-    float *prediction = network_predict(net, sized.data);
-    if (own) ::free_image(sized);
+    float *prediction = y2_network_predict_device(net, NULL);
     if (!prediction) throw std::runtime_error(y2_last_error());
     layer l = last;
     std::memcpy(st.predictions[st.demo_index].data(), prediction, (size_t)l.outputs * sizeof(float));
