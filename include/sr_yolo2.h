@@ -166,6 +166,8 @@ void cuda_set_device(int n);
 network parse_network_cfg(char *filename);                       /* parser.c:585 */
 void load_weights(network *net, char *filename);                 /* parser.c:1084 */
 void load_weights_upto(network *net, char *filename, int cutoff);/* parser.c:1009 */
+void denormalize_convolutional_layer(layer l);                   /* convolutional_layer.c:321 */
+void y2_denormalize_network(network *net);                       /* darknet.c:309-345 denormalize_net, conv layers */
 void save_weights(network net, char *filename);                  /* parser.c:878  (version 0.1 header) */
 void save_weights_upto(network net, char *filename, int cutoff); /* parser.c:822 */
 

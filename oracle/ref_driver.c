@@ -245,6 +245,26 @@ static int cmd_evalw(int argc, char **argv)
     return 0;
 }
 
+/* denorm <cfg> <weights> <out.weights>: the reference's weight surgery, denormalize_net (darknet.c:309-345) for the
+ * convolutional layers: denormalize_convolutional_layer (convolutional_layer.c:321) + batch_normalize = 0 + save_weights */
+void denormalize_convolutional_layer(layer l);
+static int cmd_denorm(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    network net = parse_network_cfg(argv[2]);
+    load_weights(&net, argv[3]);
+    int i;
+    for (i = 0; i < net.n; ++i) {
+        layer l = net.layers[i];
+        if (l.type == CONVOLUTIONAL && l.batch_normalize) {
+            denormalize_convolutional_layer(l);
+            net.layers[i].batch_normalize = 0;
+        }
+    }
+    save_weights(net, argv[4]);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: ref_driver net|time|prim ...\n"); return 2; }
@@ -252,5 +272,6 @@ int main(int argc, char **argv)
     if (!strcmp(argv[1], "time")) return cmd_time(argc, argv);
     if (!strcmp(argv[1], "prim")) return cmd_prim(argc, argv);
     if (!strcmp(argv[1], "evalw")) return cmd_evalw(argc, argv);
+    if (!strcmp(argv[1], "denorm")) return cmd_denorm(argc, argv);
     return 2;
 }

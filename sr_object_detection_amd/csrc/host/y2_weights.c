@@ -13,6 +13,7 @@
  * engine re-packs them into the kernel layout and uploads them at the next
  * predict (y2_engine.c upload_weights).
  */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -98,6 +99,39 @@ void save_weights_upto(network net, char *filename, int cutoff)
         fwrite(l->weights, sizeof(float), (size_t)l->n * l->c * l->size * l->size, fp);
     }
     fclose(fp);
+}
+
+/* convolutional_layer.c:321-334: fold the batch-norm statistics into weights and biases (weight-file surgery for
+ * `darknet denormalize`, darknet.c:309).  Note the reference's own constant here, sqrt(var + .00001), differs from
+ * the forward pass's sqrt(var) + .000001f.  The caller clears batch_normalize afterwards, as denormalize_net does. */
+void denormalize_convolutional_layer(layer l)
+{
+    int i, j;
+    const int per = l.c * l.size * l.size;
+    if (l.type != CONVOLUTIONAL || !l.weights || !l.scales) return;
+    for (i = 0; i < l.n; ++i) {
+        float scale = l.scales[i] / sqrt(l.rolling_variance[i] + .00001);
+        for (j = 0; j < per; ++j) l.weights[(size_t)i * per + j] *= scale;
+        l.biases[i] -= l.rolling_mean[i] * scale;
+        l.scales[i] = 1;
+        l.rolling_mean[i] = 0;
+        l.rolling_variance[i] = 1;
+    }
+    if (l.dev && ((y2_ldev *)l.dev)->eng) ((y2_ldev *)l.dev)->eng->weights_dirty = 1;   /* re-pack at the next forward */
+}
+
+/* darknet.c:309-345 denormalize_net for the layer types this engine has */
+void y2_denormalize_network(network *net)
+{
+    int i;
+    for (i = 0; i < net->n; ++i) {
+        layer l = net->layers[i];
+        if (l.type == CONVOLUTIONAL && l.batch_normalize) {
+            denormalize_convolutional_layer(l);
+            net->layers[i].batch_normalize = 0;
+        }
+    }
+    y2_engine_invalidate(net);      /* the arena layout depends on batch_normalize */
 }
 
 void save_weights(network net, char *filename) { save_weights_upto(net, filename, net.n); }

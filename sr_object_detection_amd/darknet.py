@@ -122,6 +122,7 @@ def lib():
     L.load_weights.argtypes = [C.POINTER(CNetwork), C.c_char_p]
     L.load_weights_upto.argtypes = [C.POINTER(CNetwork), C.c_char_p, C.c_int]
     L.save_weights.argtypes = [CNetwork, C.c_char_p]
+    L.y2_denormalize_network.argtypes = [C.POINTER(CNetwork)]
     L.set_batch_network.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.resize_network.argtypes = [C.POINTER(CNetwork), C.c_int, C.c_int]
     L.free_network.argtypes = [CNetwork]
@@ -252,6 +253,10 @@ class Network:
         lib().save_weights(self.net, filename.encode())
 
     # --- network.h ---
+    def denormalize(self) -> None:
+        """darknet.c:309 denormalize_net: fold batch-norm into weights/biases of every conv layer, clear the flag."""
+        lib().y2_denormalize_network(C.byref(self.net))
+
     def set_batch_network(self, b: int) -> None:
         lib().set_batch_network(C.byref(self.net), b)
 

@@ -46,5 +46,24 @@ def main():
                                                          fix["imagenet"].size))
 
 
+def denorm():
+    """denormalize_net (darknet.c:309 + convolutional_layer.c:321) of the compiled reference on the mini net:
+    tests/golden/denorm_mini.npz holds the bytes of the weight file it saved."""
+    sys.path.insert(0, ROOT)
+    from sr_object_detection_amd import synth, zoo
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = os.path.join(tmp, "mini.cfg")
+        open(cfg, "w").write(zoo.cfg_text("mini", 32, 32, 1))
+        wts = os.path.join(tmp, "mini.weights")
+        synth.write_weights(wts, zoo.resolve("mini", 32), 77)
+        out = os.path.join(tmp, "denorm.weights")
+        subprocess.check_call([REF_DRIVER, "denorm", cfg, wts, out], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        data = np.frombuffer(open(out, "rb").read(), dtype=np.uint8)
+    path = os.path.join(ROOT, "tests", "golden", "denorm_mini.npz")
+    np.savez_compressed(path, seed=77, size=32, weights=data)
+    print("wrote %s: %d bytes of denormalized weights" % (path, data.size))
+
+
 if __name__ == "__main__":
     main()
+    denorm()

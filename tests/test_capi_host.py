@@ -12,7 +12,7 @@ import pytest
 
 from sr_object_detection_amd import darknet, zoo
 from tests.conftest import REFERENCE_ROOT, has_gpu
-from tests.helpers import materialize
+from tests.helpers import load_golden, materialize
 
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
 
@@ -189,4 +189,23 @@ def test_gpu_index_negative_is_rejected(workdir):
     net = darknet.Network.parse_network_cfg(cfg, gpu=-1)
     with pytest.raises(darknet.Y2Error, match="no CPU compute path|no HIP device|cannot run"):
         net.network_predict(x)
+    net.free()
+
+
+def test_denormalize_net_writes_the_reference_weight_file(workdir):
+    """darknet.c:309 denormalize_net + convolutional_layer.c:321: the weight file saved after folding batch-norm
+    must equal, byte for byte, the one the compiled reference saved (tests/golden/denorm_mini.npz)."""
+    from sr_object_detection_amd import synth
+    g = load_golden("denorm_mini")
+    cfg = os.path.join(workdir, "denorm_mini.cfg")
+    open(cfg, "w").write(zoo.cfg_text("mini", int(g["size"]), int(g["size"]), 1))
+    wts = os.path.join(workdir, "denorm_mini_in.weights")
+    synth.write_weights(wts, zoo.resolve("mini", int(g["size"])), int(g["seed"]))
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    net.denormalize()
+    assert all(net.layer(i).batch_normalize == 0 for i in range(net.n))
+    out = os.path.join(workdir, "denorm_mini_out.weights")
+    net.save_weights(out)
+    assert open(out, "rb").read() == bytes(g["weights"])
     net.free()

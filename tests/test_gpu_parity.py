@@ -245,3 +245,19 @@ def test_detector_hand_off_matches_oracle(oracle, workdir):
     assert len(objs2) == len(want2)
     net.free()
     on.close()
+
+
+def test_denormalized_network_predicts_the_same(workdir):
+    """y2_denormalize_network (darknet.c:309) folds BN into the weights: the engine must re-pack them and the
+    region tensor must stay put up to the reference's own constant mismatch (sqrt(var + 1e-5) in
+    convolutional_layer.c:325 vs sqrt(var) + 1e-6 in the forward pass)."""
+    g = load_golden("mini_mfma_64_b2")
+    cfg, wts, x = materialize(workdir, "mini-mfma", 64, 2, int(g["seed"]), float(g["head_gain"]))
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    before = net.network_predict(x).copy()
+    net.denormalize()
+    after = net.network_predict(x)
+    assert all(net.layer(i).batch_normalize == 0 for i in range(net.n))
+    assert np.abs(after - before).max() < 2e-3 and not np.array_equal(after, before)
+    net.free()
