@@ -229,6 +229,10 @@ def main():
     net.set_timing(True)
     flops = conv_layer_flops(net)
     kernels = {i: net.layer_kernel(i) for i in range(net.n)}
+    if rank == 0 and os.environ.get("Y2_BENCH_DUMP_KERNELS"):
+        # conv launches of one step in order, for tools/pmc_summary.py to label rocprofv3 rows with
+        with open(os.environ["Y2_BENCH_DUMP_KERNELS"], "w") as f:
+            json.dump([kernels[i] for i in sorted(flops)], f)
     per_kernel_ms = {}
     per_kernel_flops = {}
     per_kernel_launches = {}

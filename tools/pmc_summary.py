@@ -2,9 +2,17 @@
 """Summarise rocprofv3 --pmc passes (counter_collection + kernel_trace CSVs) per conv launch of the last
 step: effective clock (GRBM_GUI_ACTIVE/8/duration), MFMA pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES over
 1024 SIMDs x clock x duration), HBM bytes (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes; the x2 is the gfx950
-FETCH_SIZE correction of MI355X_MICROARCH.md), L2 hit rate.  usage: pmc_summary.py <dir> [prefixes...]"""
+FETCH_SIZE correction of MI355X_MICROARCH.md), L2 hit rate.
+
+usage: pmc_summary.py <dir> [--names layer_kernels.json] [--json out.json] [--workload text]
+  <dir> holds p1_* (GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES), p2_* (FETCH_SIZE TCC_HIT_sum), p3_* (WRITE_SIZE
+  TCC_MISS_sum), each from its own `rocprofv3 --kernel-trace --pmc ... -- python3 bench.py ...` run.
+  --names: the ordered engine kernel names of one step's conv launches (bench.py with Y2_BENCH_DUMP_KERNELS=file);
+  with it the rows are labelled with the names bench.py reports and --json writes the per-kernel HBM bytes per
+  launch that bench.py's roofline.traffic reads (profiles/r*_pmc_traffic.json)."""
 import collections
 import csv
+import json
 import sys
 
 
@@ -22,19 +30,39 @@ def load(d, tag):
 
 
 def main():
-    d = sys.argv[1]
+    args = sys.argv[1:]
+    d = args[0]
+    names = json.load(open(args[args.index("--names") + 1])) if "--names" in args else None
+    out_json = args[args.index("--json") + 1] if "--json" in args else None
+    workload = args[args.index("--workload") + 1] if "--workload" in args else ""
     p1, p2, p3 = load(d, "p1"), load(d, "p2"), load(d, "p3")
-    print("%-36s %8s %6s %6s %9s %9s %6s" % ("kernel", "us", "GHz", "mfma%", "fetchMB", "writeMB", "L2hit"))
-    for a, b, c in zip(p1, p2, p3):
+    if names is not None and len(names) != len(p1):
+        sys.exit("--names lists %d conv launches, the profile has %d" % (len(names), len(p1)))
+    print("%-44s %8s %6s %6s %9s %9s %6s" % ("kernel", "us", "GHz", "mfma%", "fetchMB", "writeMB", "L2hit"))
+    agg = collections.OrderedDict()
+    for i, (a, b, c) in enumerate(zip(p1, p2, p3)):
         t = a["us"] * 1e-6
         ghz = a.get("GRBM_GUI_ACTIVE", 0) / 8 / t / 1e9
         util = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (ghz * 1e9 * t) if ghz else 0
-        fetch = 2 * b.get("FETCH_SIZE", 0) * 1024 / 1e6
-        write = c.get("WRITE_SIZE", 0) * 1024 / 1e6
+        fetch = 2 * b.get("FETCH_SIZE", 0) * 1024
+        write = c.get("WRITE_SIZE", 0) * 1024
         hit, miss = b.get("TCC_HIT_sum", 0), c.get("TCC_MISS_sum", 0)
-        name = a["name"].replace("void ", "").replace("conv_mfma_kernel", "mfma").replace("(ConvK)", "")
-        print("%-36s %8.1f %6.2f %6.1f %9.1f %9.1f %6.2f" % (name[:36], a["us"], ghz, 100 * util, fetch, write,
+        name = names[i] if names else a["name"].replace("void ", "").replace("conv_mfma_kernel", "mfma").replace("(ConvK)", "")
+        print("%-44s %8.1f %6.2f %6.1f %9.1f %9.1f %6.2f" % (name[:44], a["us"], ghz, 100 * util, fetch / 1e6, write / 1e6,
                                                             hit / (hit + miss) if hit + miss else 0))
+        k = agg.setdefault(name, dict(launches=0, fetch=0.0, write=0.0, us=0.0, mfma=0.0))
+        k["launches"] += 1; k["fetch"] += fetch; k["write"] += write; k["us"] += a["us"]; k["mfma"] += util
+    if out_json:
+        doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, summarised by tools/pmc_summary.py; "
+                         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); KB -> bytes; "
+                         + workload + ", last step of the run",
+               "kernels": {n: {"launches": v["launches"],
+                               "fetch_bytes_per_launch": v["fetch"] / v["launches"],
+                               "write_bytes_per_launch": v["write"] / v["launches"],
+                               "hbm_bytes_per_launch": (v["fetch"] + v["write"]) / v["launches"],
+                               "avg_launch_us": v["us"] / v["launches"],
+                               "mfma_busy": v["mfma"] / v["launches"]} for n, v in agg.items()}}
+        json.dump(doc, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
