@@ -135,3 +135,36 @@ def map_equiv(candidate_dir: str, reference_dir: str, names, min_score: float = 
         aps[name] = evaluate_class(ids, sc[keep], bx[keep], gt, **kw)[2]
     vals = [v for v in aps.values() if not np.isnan(v)]
     return (float(np.mean(vals)) if vals else float("nan")), aps
+
+
+def detections_from_dense(boxes: np.ndarray, probs: np.ndarray, thresh: float, scale_w: float, scale_h: float):
+    """Detector semantics (yolo_v2_class.cpp:221-238): per box the best class, kept when its score exceeds thresh.
+    boxes [total][4] relative centre form, probs [total][classes] after NMS -> rows (class, score, xmin, ymin, xmax, ymax)."""
+    rows = []
+    if len(boxes):
+        cls = probs.argmax(1)
+        sc = probs[np.arange(len(boxes)), cls]
+        for i in np.nonzero(sc > thresh)[0]:
+            x, y, w, h = (float(v) for v in boxes[i])
+            rows.append((int(cls[i]), float(sc[i]), (x - w / 2) * scale_w, (y - h / 2) * scale_h,
+                         (x + w / 2) * scale_w, (y + h / 2) * scale_h))
+    return rows
+
+
+def map_equiv_rows(candidate_by_image: dict, reference_by_image: dict, **kw):
+    """mAP of candidate detections with the reference detections as ground truth.  Both: {image_id: rows as
+    returned by detections_from_dense}.  -> (mAP, n_reference_detections)"""
+    classes = sorted({r[0] for rows in reference_by_image.values() for r in rows})
+    aps = []
+    for c in classes:
+        truth = {img: np.array([r[2:6] for r in rows if r[0] == c]) for img, rows in reference_by_image.items()
+                 if any(r[0] == c for r in rows)}
+        ids, sc, bx = [], [], []
+        for img, rows in candidate_by_image.items():
+            for r in rows:
+                if r[0] == c:
+                    ids.append(img); sc.append(r[1]); bx.append(r[2:6])
+        aps.append(evaluate_class(ids, sc, np.array(bx).reshape(-1, 4), truth, **kw)[2])
+    vals = [v for v in aps if not np.isnan(v)]
+    n_ref = sum(len(v) for v in reference_by_image.values())
+    return (float(np.mean(vals)) if vals else float("nan")), n_ref
