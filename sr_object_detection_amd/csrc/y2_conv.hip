@@ -6,7 +6,12 @@
 // (src_yolo2/convolutional_kernels.cu:77-131, batchnorm_layer.c:194-197), whose
 // CPU semantics are convolutional_layer.c:435-474 + blas.c:115-126.
 //
-// Two kernels:
+// Kernels (fp32; the fp16-storage variants live in y2_conv_f16.hip):
+//
+//  * conv_first_kernel -- the 3-channel first layer (K = 27): no LDS, haloed input, 14 MFMAs per 32
+//    pixels, optional fused 2x2 maxpool; HBM bound.
+//
+//  * splitk_reduce_kernel -- second pass of layers whose K loop was cut across workgroups.
 //
 //  * conv_mfma_kernel -- implicit GEMM on the fp32 matrix cores
 //    (v_mfma_f32_32x32x2_f32).  out[pixel][cout] = sum_k patch[pixel][k] *
@@ -18,7 +23,11 @@
 //    the buffer-load range check) and a [BN filters][BK] slice of the packed
 //    weights into LDS, double buffered, while the previous slice is consumed
 //    by MFMAs.  LDS rows are padded to BK+4 floats so the ds_read_b128 fragment
-//    reads (one per 4 MFMA k-steps) are bank-conflict free.
+//    reads (one per 4 MFMA k-steps) are bank-conflict free.  Workgroups are
+//    persistent (tiles b, b+G, ...; staging runs one slice ahead across tile
+//    boundaries), a following 2x2/2 maxpool is taken in the epilogue (GEMM rows in
+//    pool-major order: a window = four registers of one lane), and grids too
+//    small for 256 CUs are cut along K (split-K through an fp32 workspace).
 //    The MFMA is an exact k-ordered fp32 fma chain, so results differ from the
 //    CPU path (separately rounded mul+add, ci-major k order) only by ordinary
 //    fp32 summation noise (~1e-6 relative).

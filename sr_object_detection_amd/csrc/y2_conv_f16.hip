@@ -18,6 +18,15 @@
 // lane of a 32x32x16 MFMA) are bank-conflict free.
 #include "y2_conv_shared.hpp"
 
+// Tuning ablations (profiles/r01_notes.md): build with -DY2_F16_ABLATE and set Y2_DBG to a mask of
+// 1 no LDS staging writes, 2 no global loads, 4 no output stores, 8 scalar output stores, 16 no barrier,
+// 32 no fragment reads.  Results are garbage; compiled out by default so the K loop carries no extra branches.
+#ifdef Y2_F16_ABLATE
+#define ABL(bit) (a.dbg & (bit))
+#else
+#define ABL(bit) false
+#endif
+
 template <int BM, int BN, int BK, int KS, int WM, int WN, int MINB, bool DB>
 __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK a)
 {
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
             for (int kg = 0; kg < NG; ++kg) {
                 const int c = DB ? (kg & 1) : 0, n = DB ? (c ^ 1) : 0;
                 if (!DB) {
-                    if (!(a.dbg & 32) || kt == 0) {
+                    if (!ABL(32) || kt == 0) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[0][i] = *(const f16x8 *)&As[i * 32 * LS + kg * 16];
 #pragma unroll
@@ -182,15 +191,16 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bf[n][j] = *(const f16x8 *)&Bs[j * 32 * LS + (kg + 1) * 16];
                 }
-                // (a.dbg: tuning ablations -- 1 no LDS writes, 2 no global loads, 4 no output stores; results are garbage)
-                if (kg == 0 && !(a.dbg & 1)) store_slice(cur ^ 1);     // the slice loaded one step ago
-                if (kg == 1 && !(a.dbg & 2)) load_slice();             // two slices ahead
-                if (kg == 1 && (a.dbg & 2)) ++stage_k;
+                if (kg == 0 && !ABL(1)) store_slice(cur ^ 1);     // the slice loaded one step ago
+                if (kg == 1 && !ABL(2)) load_slice();             // two slices ahead
+                if (kg == 1 && ABL(2)) ++stage_k;
+                if (!DB) __builtin_amdgcn_s_setprio(2);     // matrix issue ahead of the partner wave's staging traffic
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+                if (!DB) __builtin_amdgcn_s_setprio(0);
                 // issue order inside the group: one MFMA first, the fragment reads of the next group, then
                 // the staging work spread one piece per MFMA
                 if (DB) {
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!(a.dbg & 16)) __syncthreads();
+            if (!ABL(16)) __syncthreads();
             cur ^= 1;
         }
 
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
                         }
                         const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
                         const int prow = (pb >> 2) + rrow;
-                        if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout && !(a.dbg & 4))
+                        if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout && !ABL(4))
                             *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
                     } else {
 #pragma unroll
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
                         for (int h2 = 0; h2 < 2; ++h2) {
                             const f32x4 v = *(const f32x4 *)&es[(rrow + 16 * h2) * ES + rchunk];
                             const int p = pb + rrow + 16 * h2;
-                            if (p < a.npix && cb + rchunk < a.Cout && !(a.dbg & 4)) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
+                            if (p < a.npix && cb + rchunk < a.Cout && !ABL(4)) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
                         }
                     }
                 }
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int co = n0 + wn * (BN / WN) + j * 32 + li;
-            const bool cok = co < a.Cout && !(a.dbg & 4);
+            const bool cok = co < a.Cout && !ABL(4);
             const float alpha = cok ? a.alpha[co] : 0.f, beta = cok ? a.beta[co] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -415,7 +425,7 @@ int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     a.tiles_n = (d->n + v->bn - 1) / v->bn;
     a.ksplit = 1;
     if (const char *dbg = getenv("Y2_DBG")) a.dbg = atoi(dbg);
-    a.vec_store = d->y_f16 && d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !(a.dbg & 8);
+    a.vec_store = d->y_f16 && d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !ABL(8);
     const long tiles_m = ((long)a.npix + v->bm - 1) / v->bm;
     int dev = 0;
     Y2H_CHECK(hipGetDevice(&dev));
