@@ -204,6 +204,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // a wave in its K loop outranks co-resident waves that are in their (VALU / store) epilogue or tile setup
+    __builtin_amdgcn_s_setprio(1);
     for (int kt = kb; kt < ke; ++kt) {
         if (kt == ke - 1) {
             // the slice fetched during this (last) K-step is the first one of the block's next work
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         __syncthreads();
         cur ^= 1;
     }
+    __builtin_amdgcn_s_setprio(0);
 
     // epilogue: lane holds column (cout) li of each 32x32 tile and 16 rows (pixels)
 #pragma unroll
