@@ -224,7 +224,19 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!ABL(16)) __syncthreads();
+            // Raw barrier: wait for this wave's LDS traffic only.  __syncthreads() would also drain vmcnt(0), i.e.
+            // wait at every K-step for the global loads of the slice two steps ahead that were just issued --
+            // the latency the two-slice distance exists to hide.
+#ifdef Y2_F16_SYNCTHREADS
+            __syncthreads();
+#else
+            if (!ABL(16)) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             cur ^= 1;
         }
 

@@ -23,7 +23,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsr_yolo2.so")
+# Y2_LIB points at another build of the same library (A/B runs of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("Y2_LIB") or os.path.join(_HERE, "libsr_yolo2.so")
 
 
 class Y2Error(RuntimeError):
