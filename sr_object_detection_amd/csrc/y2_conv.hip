@@ -311,10 +311,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r0 = prow + 8 * g;              // first of the window's four rows
-                    float m = epilogue(acc[i][j][4 * g], a.bn, mean, rinv, scale, bias, a.act);
+                    float m = epilogue_f32(acc[i][j][4 * g], a.bn, mean, rinv, scale, bias, a.act);
 #pragma unroll
                     for (int t = 1; t < 4; ++t) {
-                        const float v = epilogue(acc[i][j][4 * g + t], a.bn, mean, rinv, scale, bias, a.act);
+                        const float v = epilogue_f32(acc[i][j][4 * g + t], a.bn, mean, rinv, scale, bias, a.act);
                         m = (v > m) ? v : m;
                     }
                     if (cok && r0 < a.npix) a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                 for (int r = 0; r < 16; ++r) {
                     const int p = prow + (r & 3) + 8 * (r >> 2);
                     if (cok && p < a.npix)
-                        a.y[(size_t)p * a.ldy + co] = epilogue(acc[i][j][r], a.bn, mean, rinv, scale, bias, a.act);
+                        a.y[(size_t)p * a.ldy + co] = epilogue_f32(acc[i][j][r], a.bn, mean, rinv, scale, bias, a.act);
                 }
             }
         }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK a)
         float mean = 0.f, scale = 1.f;
         double rinv = 1.0;
         if (a.bn) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
-        a.y[(size_t)p * a.ldy + co] = epilogue(sum, a.bn, mean, rinv, scale, a.bias[co], a.act);
+        a.y[(size_t)p * a.ldy + co] = epilogue_f32(sum, a.bn, mean, rinv, scale, a.bias[co], a.act);
     }
 }
 
@@ -446,10 +446,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const long r0 = prow + 8 * g;
-                    float m = epilogue(acc[j][4 * g], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+                    float m = epilogue_f32(acc[j][4 * g], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
 #pragma unroll
                     for (int t = 1; t < 4; ++t) {
-                        const float v = epilogue(acc[j][4 * g + t], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+                        const float v = epilogue_f32(acc[j][4 * g + t], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
                         m = (v > m) ? v : m;
                     }
                     if (co < a.Cout && r0 < a.npix) {
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
             for (int r = 0; r < 16; ++r) {
                 const long p = prow + (r & 3) + 8 * (r >> 2);
                 if (co < a.Cout && p < a.npix) {
-                    const float v = epilogue(acc[j][r], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+                    const float v = epilogue_f32(acc[j][r], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
                     if (a.y_f16) ((_Float16 *)a.y)[(size_t)p * a.ldy + co] = (_Float16)v;
                     else a.y[(size_t)p * a.ldy + co] = v;
                 }

@@ -49,6 +49,27 @@ __device__ __forceinline__ float epilogue(float v, bool bn, float mean, double r
     return v;
 }
 
+// Build option -DY2_FAST_EPILOGUE: the same steps in fp32 arithmetic for the matrix-core kernels (at most 2 ulp from
+// epilogue()).  Measured on yolo.cfg 608 b32: +0.5-0.9 % images/s (A/B on one box) -- not worth leaving the reference's
+// arithmetic, so the default keeps the exact form everywhere.
+__device__ __forceinline__ float epilogue_f32(float v, bool bn, float mean, double rinv, float scale, float bias, int act)
+{
+#ifndef Y2_FAST_EPILOGUE
+    return epilogue(v, bn, mean, rinv, scale, bias, act);
+#else
+    if (bn) {
+        float d = v - mean;
+        v = d * (float)rinv;
+        v = v * scale;
+    }
+    v = v + bias;
+    if (act == Y2H_ACT_LEAKY) v = (v > 0) ? v : .1f * v;
+    else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));
+    else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);
+    return v;
+#endif
+}
+
 // fp16 path: BN folded into one fma on the fp32 accumulator (alpha = scale/(sqrt(var)+1e-6), beta = bias - mean*alpha),
 // fp32 activation.  There is no reference arithmetic to mirror here: the reference has no half path.
 __device__ __forceinline__ float epilogue_fast(float v, float alpha, float beta, int act)

@@ -18,6 +18,7 @@
 #include <limits>
 
 #include "sr_yolo2.h"
+#include "y2_hip.h"
 
 extern "C" void y2_set_error_mode(int mode);
 
@@ -53,10 +54,20 @@ bbox_t to_bbox(float bx, float by, float bw, float bh, float prob, int cls, int 
     return r;
 }
 
+// The reference saves the caller's current device around the constructor, detect() and the destructor and
+// restores it afterwards (cpp:41,48,79,99-108,178-181,245), so that several Detectors on different GPUs can be
+// driven from one thread; the engine selects its own device on every call, this puts the caller's back.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (y2h_device_count() > 0 && y2h_get_device(&saved) != 0) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) y2h_set_device(saved); }
+};
+
 }  // namespace
 
 Detector::Detector(std::string cfg_filename, std::string weight_filename, int gpu_id)
 {
+    DeviceGuard guard;
     auto *st = new DetectorState();
     detector_gpu_ptr = std::shared_ptr<void>(st, [](void *p) { delete static_cast<DetectorState *>(p); });
     const int saved = gpu_index;
@@ -81,6 +92,7 @@ Detector::Detector(std::string cfg_filename, std::string weight_filename, int gp
 
 Detector::~Detector()
 {
+    DeviceGuard guard;
     if (detector_gpu_ptr) free_network(state_of(detector_gpu_ptr).net);
 }
 
@@ -137,6 +149,7 @@ std::vector<bbox_t> Detector::detect(std::string image_filename, float thresh, b
 
 std::vector<bbox_t> Detector::detect(image_t img, float thresh, bool use_mean)
 {
+    DeviceGuard guard;
     DetectorState &st = state_of(detector_gpu_ptr);
     network &net = st.net;
     if (!img.data) throw std::runtime_error("Image is empty");
@@ -181,6 +194,7 @@ std::vector<bbox_t> Detector::detect(image_t img, float thresh, bool use_mean)
 
 std::vector<bbox_t> Detector::detect_frame(const unsigned char *data, int w, int h, int c, int step, float thresh, bool bgr)
 {
+    DeviceGuard guard;
     DetectorState &st = state_of(detector_gpu_ptr);
     network &net = st.net;
     if (!data) throw std::runtime_error("Image is empty");

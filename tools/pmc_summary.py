@@ -38,7 +38,7 @@ def main():
     p1, p2, p3 = load(d, "p1"), load(d, "p2"), load(d, "p3")
     if names is not None and len(names) != len(p1):
         sys.exit("--names lists %d conv launches, the profile has %d" % (len(names), len(p1)))
-    print("%-44s %8s %6s %6s %9s %9s %6s" % ("kernel", "us", "GHz", "mfma%", "fetchMB", "writeMB", "L2hit"))
+    print("%-44s %8s %6s %6s %9s %9s %8s %6s" % ("kernel", "us", "GHz", "mfma%", "fetchMB", "writeMB", "HBM GB/s", "L2hit"))
     agg = collections.OrderedDict()
     for i, (a, b, c) in enumerate(zip(p1, p2, p3)):
         t = a["us"] * 1e-6
@@ -48,8 +48,8 @@ def main():
         write = c.get("WRITE_SIZE", 0) * 1024
         hit, miss = b.get("TCC_HIT_sum", 0), c.get("TCC_MISS_sum", 0)
         name = names[i] if names else a["name"].replace("void ", "").replace("conv_mfma_kernel", "mfma").replace("(ConvK)", "")
-        print("%-44s %8.1f %6.2f %6.1f %9.1f %9.1f %6.2f" % (name[:44], a["us"], ghz, 100 * util, fetch / 1e6, write / 1e6,
-                                                            hit / (hit + miss) if hit + miss else 0))
+        print("%-44s %8.1f %6.2f %6.1f %9.1f %9.1f %8.0f %6.2f" % (name[:44], a["us"], ghz, 100 * util, fetch / 1e6, write / 1e6,
+                                                                  (fetch + write) / 1e9 / t, hit / (hit + miss) if hit + miss else 0))
         k = agg.setdefault(name, dict(launches=0, fetch=0.0, write=0.0, us=0.0, mfma=0.0))
         k["launches"] += 1; k["fetch"] += fetch; k["write"] += write; k["us"] += a["us"]; k["mfma"] += util
     if out_json:
