@@ -273,6 +273,10 @@ int y2_forward_device(network net, const float *d_input);
  * detections per image are written to dets[b*max_per_image ...], counts[b] = number found. */
 int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_h,
                        y2_det *dets, int *counts, int max_per_image);
+/* Same on the average of the last three forwards' region outputs (Detector::detect use_mean, yolo_v2_class.cpp:
+ * 208-213): the three-slot ring and the average live in HBM; slots start zeroed like the reference's calloc. */
+int y2_detect_mean(network net, float thresh, float nms, int img_w, int img_h,
+                   y2_det *dets, int *counts, int max_per_image);
 /* Host-input convenience: H2D + forward + y2_detect_resident. */
 int y2_detect(network net, float *input, float thresh, float nms, int img_w, int img_h,
               y2_det *dets, int *counts, int max_per_image);

@@ -212,6 +212,10 @@ int y2h_collect(const float *boxes, const float *probs, int batch, int total, in
                 float thresh, float *records, int *counts, int max_per_image,
                 float *best_scratch /* device, 2*batch*total floats */, y2h_stream s);
 
+/* avg[i] = (0 + f[0][i] + f[1][i] + ... ) / n over n frames of `els` floats laid out back to back, summed in frame
+ * order like utils.c:420-432 mean_arrays */
+int y2h_mean_frames(const float *frames, int n, long els, float *avg, y2h_stream s);
+
 /* separable align-corners bilinear resize of a CHW image (image.c:1950-1992) */
 int y2h_resize_chw(const float *src, int c, int ih, int iw, float *tmp, float *dst, int h, int w, y2h_stream s);
 

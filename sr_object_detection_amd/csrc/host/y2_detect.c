@@ -236,7 +236,7 @@ image resize_image(image im, int w, int h)   /* image.c:1950-1992, on the device
 /* ------------------------------------------------------------------ */
 /* fused, HBM-resident detection                                       */
 /* ------------------------------------------------------------------ */
-int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_h,
+static int detect_from(network net, float *d_pred, float thresh, float nms, int img_w, int img_h,
                        y2_det *dets, int *counts, int max_per_image)
 {
     y2_engine *e = y2_engine_of(&net);
@@ -250,13 +250,14 @@ int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_
     d = ld_of(l);
     if (l->type != REGION) { y2_fail("y2_detect_resident: the network does not end in a region layer"); return -1; }
     HIPCALL_I(y2h_set_device(e->device));
+    if (!d_pred) d_pred = d->d_region;
     memset(&q, 0, sizeof q);
     q.batch = net.batch; q.w = l->w; q.h = l->h; q.num = l->n; q.classes = l->classes;
     q.img_w = img_w; q.img_h = img_h; q.thresh = thresh; q.classfix = l->classfix;
     q.anchors = d->d_anchors;
     q.tree_parent = l->softmax_tree ? d->d_tree_parent : NULL;
     q.tree_order = d->d_tree_order; q.tree_level_off = d->d_tree_loff; q.tree_levels = d->tree_levels;
-    q.pred = d->d_region; q.boxes = e->d_boxes; q.probs = e->d_probs;
+    q.pred = d_pred; q.boxes = e->d_boxes; q.probs = e->d_probs;
     HIPCALL_I(y2h_region_boxes(&q, e->stream));
     final_probs = e->d_probs;
     if (nms > 0) {
@@ -299,6 +300,41 @@ int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_
         }
     }
     return 0;
+}
+
+int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_h,
+                       y2_det *dets, int *counts, int max_per_image)
+{
+    return detect_from(net, NULL, thresh, nms, img_w, img_h, dets, counts, max_per_image);
+}
+
+/* The 3-frame smoothing of Detector::detect(..., use_mean = true) (yolo_v2_class.cpp:208-213: memcpy into
+ * predictions[demo_index], mean_arrays over the FRAMES = 3 slots, l.output = avg, demo_index++), kept in HBM: the
+ * region output of the last forward goes into a three-slot ring that starts zeroed (the reference callocs its
+ * slots), the slots are summed in slot order and divided by 3 exactly as utils.c:420-432 does, and decode + NMS run
+ * on the average.  Batch-1 networks only, like the reference. */
+int y2_detect_mean(network net, float thresh, float nms, int img_w, int img_h, y2_det *dets, int *counts, int max_per_image)
+{
+    y2_engine *e = y2_engine_of(&net);
+    layer *l;
+    y2_ldev *d;
+    size_t els;
+    if (!e || !e->built) { y2_fail("y2_detect_mean: run a forward first"); return -1; }
+    l = &net.layers[e->out_layer];
+    d = ld_of(l);
+    if (l->type != REGION || net.batch != 1) { y2_fail("y2_detect_mean: needs a batch-1 network ending in a region layer"); return -1; }
+    HIPCALL_I(y2h_set_device(e->device));
+    els = (size_t)l->outputs;
+    if (!e->d_mean_ring || e->mean_els != els) {
+        y2h_free(e->d_mean_ring); e->d_mean_ring = NULL;
+        HIPCALL_I(y2h_malloc((void **)&e->d_mean_ring, 4 * els * sizeof(float)));      /* 3 slots + the average */
+        HIPCALL_I(y2h_memset(e->d_mean_ring, 0, 4 * els * sizeof(float), e->stream));
+        e->mean_els = els; e->mean_index = 0;
+    }
+    HIPCALL_I(y2h_memcpy_d2d(e->d_mean_ring + (size_t)e->mean_index * els, d->d_region, els * sizeof(float), e->stream));
+    e->mean_index = (e->mean_index + 1) % 3;
+    HIPCALL_I(y2h_mean_frames(e->d_mean_ring, 3, (long)els, e->d_mean_ring + 3 * els, e->stream));
+    return detect_from(net, e->d_mean_ring + 3 * els, thresh, nms, img_w, img_h, dets, counts, max_per_image);
 }
 
 int y2_detect(network net, float *input, float thresh, float nms, int img_w, int img_h,

@@ -111,6 +111,7 @@ static void free_plan(network *net)
     y2h_free(e->d_counts); e->d_counts = NULL;
     y2h_free(e->d_class_counts); e->d_class_counts = NULL;
     y2h_free(e->d_best); e->d_best = NULL;
+    y2h_free(e->d_mean_ring); e->d_mean_ring = NULL; e->mean_els = 0; e->mean_index = 0;
     y2h_host_free(e->h_records); e->h_records = NULL;
     y2h_host_free(e->h_counts); e->h_counts = NULL;
     e->built = 0;

@@ -75,6 +75,9 @@ typedef struct y2_engine {
     int *d_counts;
     int *d_class_counts;       /* [batch][classes] non-zero scores (NMS skips empty classes) */
     float *d_best;             /* [2][batch][total] best score / class per box */
+    float *d_mean_ring;        /* y2_detect_mean: three region-output slots + their average (batch 1) */
+    size_t mean_els;
+    int mean_index;
     float *h_records;
     int *h_counts;
     int det_cap;               /* records per image */

@@ -103,3 +103,21 @@ extern "C" int y2h_letterbox_chw(const float *src, int c, int ih, int iw, float 
     if (rc) return rc;
     return y2h_embed_chw(resized, c, nh, nw, dst, h, w, (w - nw) / 2, (h - nh) / 2, s);
 }
+
+// utils.c:420-432 mean_arrays on device buffers: avg = 0; for j: avg += frame j; avg /= n  (fp32, frame order)
+__global__ __launch_bounds__(256) void mean_frames_kernel(const float *__restrict__ frames, int n, long els, float *__restrict__ avg)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < els; i += (long)gridDim.x * 256) {
+        float a = 0.f;
+        for (int j = 0; j < n; ++j) a += frames[(size_t)j * els + i];
+        avg[i] = a / n;
+    }
+}
+
+extern "C" int y2h_mean_frames(const float *frames, int n, long els, float *avg, y2h_stream s)
+{
+    if (!frames || !avg || n <= 0 || els <= 0) return Y2H_EINVAL;
+    hipLaunchKernelGGL(mean_frames_kernel, dim3(y2h_grid(els, 256)), dim3(256), 0, S(s), frames, n, els, avg);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

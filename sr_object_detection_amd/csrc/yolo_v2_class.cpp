@@ -5,9 +5,9 @@
 //                        do_nms_sort(nms) -> bbox_t conversion with unsigned truncation
 //  tracking cpp:251-303  nearest-centre (< 100 px) track-id hand-over across frames
 //
-// Without use_mean the whole chain runs as the fused HBM-resident y2_detect();
-// with use_mean the 3-frame average of the raw predictions (cpp:208-213) is
-// formed first and decoded through get_region_boxes / do_nms_sort.
+// The frame goes up once (y2_ingest_image: device-side resize into the network input) and the whole
+// chain runs HBM-resident: y2_forward_device + y2_detect_resident, or with use_mean y2_detect_mean (the
+// 3-frame ring of raw predictions, cpp:208-213, its average, decode and NMS on the device).
 #include "yolo_v2_class.hpp"
 
 #include <algorithm>
@@ -24,18 +24,11 @@ extern "C" void y2_set_error_mode(int mode);
 
 namespace {
 
-const int kFrames = 3;
 
 struct DetectorState {
     network net;
-    std::vector<float> avg;
-    std::vector<float> predictions[kFrames];
-    int demo_index = 0;
     std::vector<unsigned int> next_track_id;     // per class
-    std::vector<y2_det> dets;
-    std::vector<box> boxes;
-    std::vector<float> probs_flat;
-    std::vector<float *> probs;
+    std::vector<y2_det> dets;                    // compact detections of the last call
 };
 
 DetectorState &state_of(const std::shared_ptr<void> &p) { return *static_cast<DetectorState *>(p.get()); }
@@ -79,15 +72,8 @@ Detector::Detector(std::string cfg_filename, std::string weight_filename, int gp
     if (!weight_filename.empty()) load_weights(&st->net, const_cast<char *>(weight_filename.c_str()));
     set_batch_network(&st->net, 1);
     const layer &l = st->net.layers[st->net.n - 1];
-    st->avg.assign(l.outputs, 0.f);
-    for (auto &p : st->predictions) p.assign(l.outputs, 0.f);
     st->next_track_id.assign(std::max(l.classes, 1), 1u);
-    const int total = l.w * l.h * l.n;
-    st->dets.resize(std::max(total, 1));
-    st->boxes.resize(std::max(total, 1));
-    st->probs_flat.assign((size_t)std::max(total, 1) * std::max(l.classes, 1), 0.f);
-    st->probs.resize(std::max(total, 1));
-    for (int i = 0; i < total; ++i) st->probs[i] = st->probs_flat.data() + (size_t)i * l.classes;
+    st->dets.resize(std::max(l.w * l.h * l.n, 1));
 }
 
 Detector::~Detector()
@@ -160,34 +146,16 @@ std::vector<bbox_t> Detector::detect(image_t img, float thresh, bool use_mean)
     const layer &last = net.layers[net.n - 1];
     const int total = last.w * last.h * last.n;
     std::vector<bbox_t> out;
-    if (!use_mean) {
-        int count = 0;
-        const int rc = y2_forward_device(net, NULL) || y2_detect_resident(net, thresh, nms, 1, 1, st.dets.data(), &count, total);
-        if (rc != 0) throw std::runtime_error(y2_last_error());
-        for (int i = 0; i < std::min(count, total); ++i) {
-            const y2_det &d = st.dets[i];
-            out.push_back(to_bbox(d.x, d.y, d.w, d.h, d.prob, d.obj_id, im.w, im.h));
-        }
-        return out;
-    }
-    float *prediction = y2_network_predict_device(net, NULL);
-    if (!prediction) throw std::runtime_error(y2_last_error());
-    layer l = last;
-    std::memcpy(st.predictions[st.demo_index].data(), prediction, (size_t)l.outputs * sizeof(float));
-    float *rows[kFrames];
-    for (int j = 0; j < kFrames; ++j) rows[j] = st.predictions[j].data();
-    mean_arrays(rows, kFrames, l.outputs, st.avg.data());
-    l.output = st.avg.data();
-    st.demo_index = (st.demo_index + 1) % kFrames;
-    get_region_boxes(l, 1, 1, thresh, st.probs.data(), st.boxes.data(), 0, 0);
-    if (nms) do_nms_sort(st.boxes.data(), st.probs.data(), total, l.classes, nms);
-    for (int i = 0; i < total; ++i) {
-        const int id = max_index(st.probs[i], l.classes);
-        const float prob = st.probs[i][id];
-        if (prob > thresh) {
-            const box &b = st.boxes[i];
-            out.push_back(to_bbox(b.x, b.y, b.w, b.h, prob, id, im.w, im.h));
-        }
+    // use_mean (cpp:208-213): the three-frame ring, its average, decode and NMS all stay in HBM (y2_detect_mean)
+    int count = 0;
+    int rc = y2_forward_device(net, NULL);
+    if (rc == 0)
+        rc = use_mean ? y2_detect_mean(net, thresh, nms, 1, 1, st.dets.data(), &count, total)
+                      : y2_detect_resident(net, thresh, nms, 1, 1, st.dets.data(), &count, total);
+    if (rc != 0) throw std::runtime_error(y2_last_error());
+    for (int i = 0; i < std::min(count, total); ++i) {
+        const y2_det &d = st.dets[i];
+        out.push_back(to_bbox(d.x, d.y, d.w, d.h, d.prob, d.obj_id, im.w, im.h));
     }
     return out;
 }

@@ -401,6 +401,18 @@ class Network:
             raise Y2Error("y2_detect_resident: " + _check())
         return [dets[b, :min(int(counts[b]), cap)].copy() for b in range(self.net.batch)], counts
 
+    def detect_mean(self, thresh: float, nms: float, img_w: int = 1, img_h: int = 1):
+        """decode + NMS of the average of the last three forwards (Detector use_mean, y2_detect_mean); batch 1"""
+        l = self.last
+        cap = l.w * l.h * l.n
+        dets = np.zeros((1, cap), dtype=DET_DTYPE)
+        counts = np.zeros(1, dtype=np.int32)
+        L = lib()
+        L.y2_detect_mean.argtypes = [CNetwork, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        if L.y2_detect_mean(self.net, thresh, nms, img_w, img_h, _ptr(dets), _ptr(counts), cap) != 0:
+            raise Y2Error("y2_detect_mean: " + _check())
+        return dets[0, :min(int(counts[0]), cap)].copy(), int(counts[0])
+
     def detect(self, x: np.ndarray, thresh: float, nms: float, img_w: int = 1, img_h: int = 1):
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
         l = self.last

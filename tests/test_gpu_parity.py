@@ -261,3 +261,40 @@ def test_denormalized_network_predicts_the_same(workdir):
     assert all(net.layer(i).batch_normalize == 0 for i in range(net.n))
     assert np.abs(after - before).max() < 2e-3 and not np.array_equal(after, before)
     net.free()
+
+
+def test_three_frame_mean_matches_oracle(oracle, workdir):
+    """Detector use_mean (yolo_v2_class.cpp:208-213): region outputs of the last three frames averaged in slot order
+    (zero slots first, utils.c:420 mean_arrays), then decode + NMS on the average -- on the device, checked against
+    the same sequence through the oracle (strict mode: bit-identical forward, so identical detections)."""
+    import ctypes as C
+    g = load_golden("mini_mfma_64_b2")
+    cfg, wts, _ = materialize(workdir, "mini-mfma", 64, 1, int(g["seed"]), float(g["head_gain"]))
+    from sr_object_detection_amd import synth
+    frames = [synth.image_batch(1, 3, 64, 64, seed=900 + k) for k in range(4)]
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    net.set_strict(True)
+    on = oracle.OracleNet(cfg, wts)
+    last = on.last
+    n = on.layer_info(last)["outputs"]
+    slots = [np.zeros(n, np.float32) for _ in range(3)]
+    thresh, nms = 0.1, 0.4
+    for k, x in enumerate(frames):
+        net.network_predict(x)
+        dets, count = net.detect_mean(thresh, nms)
+        slots[k % 3] = on.predict(x).copy()
+        avg = np.zeros(n, np.float32)
+        for s in slots:
+            avg = (avg + s).astype(np.float32)
+        avg = (avg / np.float32(3)).astype(np.float32)
+        C.memmove(on.L.orc_layer_output(on.h, last), avg.ctypes.data, avg.nbytes)      # decode the averaged tensor
+        boxes, probs = on.region_boxes(0, thresh)
+        post = oracle.do_nms_sort(boxes, probs, nms)
+        want = [(i, int(np.argmax(post[i]))) for i in range(len(boxes)) if post[i].max() > thresh]
+        assert count == len(want) and (k == 0 or count > 0)
+        for d, (i, c) in zip(dets, want):
+            assert int(d["obj_id"]) == c and float(d["prob"]) == float(post[i, c])
+            assert [float(d[key]) for key in "xywh"] == [float(v) for v in boxes[i]]
+    net.free()
+    on.close()
