@@ -143,6 +143,10 @@ int y2h_maxpool(const float *x, int ldx, float *y, int ldy, int batch, int h, in
  * layer, reorg_layer.c:83), re-expressed for NHWC in and out; reverse!=0 is forward=1 */
 int y2h_reorg(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c,
               int stride, int reverse, y2h_stream s);
+/* residual add (shortcut_layer.c:38-43, blas.c:57-81): out = act(in + add) where the shapes overlap; `add` is
+ * w1 x h1 x c1, in/out are w2 x h2 x c2; stride = w1/w2 and sample = w2/w1 (each >= 1) as in shortcut_cpu */
+int y2h_shortcut(const float *in, int ld_in, const float *add, int ld_add, float *out, int ld_out, int batch,
+                 int w1, int h1, int c1, int w2, int h2, int c2, int activation, y2h_stream s);
 /* global average pool: [batch][h*w][ld] -> [batch][c] (sequential fp32 sum, avgpool_layer.c:40) */
 int y2h_avgpool(const float *x, int ldx, float *y, int batch, int h, int w, int c, y2h_stream s);
 /* rows of `n` floats: softmax with temperature (blas.c:205); in/out may alias */

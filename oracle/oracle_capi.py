@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liby2oracle.so")
 REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
 
-KINDS = ["convolutional", "maxpool", "route", "reorg", "region", "avgpool", "softmax", "cost"]
+KINDS = ["convolutional", "maxpool", "route", "reorg", "region", "avgpool", "softmax", "cost", "shortcut"]
 
 
 def build(force: bool = False) -> str:

@@ -28,7 +28,7 @@
 #include <stdint.h>
 #include <time.h>
 
-enum { ORC_CONV = 0, ORC_MAXPOOL, ORC_ROUTE, ORC_REORG, ORC_REGION, ORC_AVGPOOL, ORC_SOFTMAX, ORC_COST };
+enum { ORC_CONV = 0, ORC_MAXPOOL, ORC_ROUTE, ORC_REORG, ORC_REGION, ORC_AVGPOOL, ORC_SOFTMAX, ORC_COST, ORC_SHORTCUT };
 enum { ACT_LOGISTIC = 0, ACT_RELU, ACT_LINEAR, ACT_LEAKY, ACT_RAMP, ACT_TANH, ACT_ELU, ACT_HARDTAN };
 
 typedef struct {
@@ -397,6 +397,20 @@ orc_net *orc_parse_cfg(const char *path)
             /* parser.c:309-317, cost_layer.c:32-55: no-op at inference (cost_layer.c:75) */
             l->kind = ORC_COST;
             l->inputs = inputs; l->outputs = inputs;
+        } else if (!strcmp(t, "[shortcut]")) {
+            /* parser.c:415-430, shortcut_layer.c:7-36: l.w/h/c = the `from` layer's output shape, out = this input's */
+            const char *fs = opt(s, "from");
+            int idx = fs ? atoi(fs) : 0;
+            if (!fs) { fprintf(stderr, "oracle: shortcut needs from=\n"); return NULL; }
+            if (idx < 0) idx = i + idx;
+            if (idx < 0 || idx >= i) { fprintf(stderr, "oracle: shortcut from=%d out of range\n", idx); return NULL; }
+            l->kind = ORC_SHORTCUT;
+            l->n = idx;                                     /* the reference's l.index */
+            l->w = net->layers[idx].out_w; l->h = net->layers[idx].out_h; l->c = net->layers[idx].out_c;
+            l->out_w = w; l->out_h = h; l->out_c = c;
+            l->outputs = w * h * c;
+            l->inputs = l->outputs;
+            l->activation = activation_from_name(opt(s, "activation") ? opt(s, "activation") : "linear");
         } else {
             fprintf(stderr, "oracle: layer type %s is outside the hot path\n", t);
             return NULL;
@@ -710,6 +724,22 @@ float *orc_predict(orc_net *net, const float *input)
         case ORC_AVGPOOL: forward_avgpool(l, cur); break;
         case ORC_SOFTMAX: forward_softmax(l, cur); break;
         case ORC_COST: break;      /* cost_layer.c:75: returns at once without truth */
+        case ORC_SHORTCUT: {       /* shortcut_layer.c:38-43: copy, shortcut_cpu (blas.c:57-81), activate_array */
+            const float *add = net->layers[l->n].output;
+            const int w1 = l->w, h1 = l->h, c1 = l->c, w2 = l->out_w, h2 = l->out_h, c2 = l->out_c;
+            int stride = w1 / w2, sample = w2 / w1, minw, minh, minc, x, y, kk;
+            size_t e, tot = (size_t)l->outputs * l->batch;
+            memcpy(l->output, cur, tot * sizeof(float));
+            if (stride < 1) stride = 1;
+            if (sample < 1) sample = 1;
+            minw = w1 < w2 ? w1 : w2; minh = h1 < h2 ? h1 : h2; minc = c1 < c2 ? c1 : c2;
+            for (b = 0; b < l->batch; ++b) for (kk = 0; kk < minc; ++kk) for (y = 0; y < minh; ++y) for (x = 0; x < minw; ++x) {
+                size_t out_index = x * sample + (size_t)w2 * (y * sample + (size_t)h2 * (kk + (size_t)c2 * b));
+                size_t add_index = x * stride + (size_t)w1 * (y * stride + (size_t)h1 * (kk + (size_t)c1 * b));
+                l->output[out_index] += add[add_index];
+            }
+            for (e = 0; e < tot; ++e) l->output[e] = act(l->output[e], l->activation);
+        } break;
         }
         cur = l->output;
     }

@@ -453,6 +453,33 @@ static layer make_route(list *o, shape p, network *net)
     return l;
 }
 
+/* parser.c:415-430 parse_shortcut + shortcut_layer.c:7-36: l.w/h/c = shape of the `from` layer's output,
+ * out = this layer's input shape, l.index = the `from` layer (the reference's field of that name) */
+static layer make_shortcut(list *o, shape p, network *net)
+{
+    layer l, *from;
+    char *fs = option_find(o, "from");
+    int idx;
+    memset(&l, 0, sizeof l);
+    l.type = SHORTCUT;
+    if (!fs) { y2_fail("Shortcut layer must specify from="); return l; }
+    idx = atoi(fs);
+    if (idx < 0) idx = p.index + idx;
+    if (idx < 0 || idx >= p.index) { y2_fail("shortcut layer %d refers to layer %d", p.index, idx); return l; }
+    if (!(p.h && p.w && p.c)) { y2_fail("Layer before shortcut layer must output image."); return l; }
+    from = &net->layers[idx];
+    if (!(from->out_h && from->out_w && from->out_c)) { y2_fail("shortcut layer %d: layer %d does not output an image", p.index, idx); return l; }
+    l.index = idx;
+    l.batch = p.batch;
+    l.w = from->out_w; l.h = from->out_h; l.c = from->out_c;
+    l.out_w = p.w; l.out_h = p.h; l.out_c = p.c;
+    l.outputs = p.w * p.h * p.c;
+    l.inputs = l.outputs;
+    l.activation = activation_by_name(option_find_str(o, "activation", "linear"));
+    fprintf(stderr, "Shortcut Layer: %d\n", idx);
+    return l;
+}
+
 static layer make_reorg(list *o, shape p)
 {
     layer l;
@@ -648,6 +675,7 @@ network parse_network_cfg(char *filename)    /* parser.c:585-700 */
         else if (is_type(t, "[maxpool]", "[max]")) l = make_maxpool(s->options, p);
         else if (is_type(t, "[route]", NULL)) l = make_route(s->options, p, &net);
         else if (is_type(t, "[reorg]", NULL)) l = make_reorg(s->options, p);
+        else if (is_type(t, "[shortcut]", NULL)) l = make_shortcut(s->options, p, &net);
         else if (is_type(t, "[region]", NULL)) l = make_region(s->options, p);
         else if (is_type(t, "[avgpool]", "[avg]")) l = make_avgpool(p);
         else if (is_type(t, "[softmax]", "[soft]")) { l = make_softmax(s->options, p); net.hierarchy = l.softmax_tree; }
@@ -657,7 +685,7 @@ network parse_network_cfg(char *filename)    /* parser.c:585-700 */
             y2_fail("layer type %s is outside the YOLOv2/Darknet-19 forward path this engine implements", t);
         }
         if (y2_failed()) { g_flag = 1; return empty; }
-        l.index = count;
+        if (l.type != SHORTCUT) l.index = count;      /* a shortcut keeps the index of its `from` layer there */
         l.dontload = option_find_int_quiet(s->options, "dontload", 0);
         l.dontloadscales = option_find_int_quiet(s->options, "dontloadscales", 0);
         report_unused(s->options);

@@ -348,9 +348,11 @@ int y2_engine_build(network *net)
             if (l->stride != 1 || l->pad != l->size / 2 || !(l->size == 1 || l->size == 3)) continue;
             if (!((l->c % 16 == 0) || (i == 0 && l->c == 3 && l->size == 3 && l->n <= 64))) continue;
             if (i == e->out_layer || ld_of(l)->placed_in >= 0) continue;
-            for (j = 0; j < net->n; ++j)
+            for (j = 0; j < net->n; ++j) {
                 if (net->layers[j].type == ROUTE)
                     for (k = 0; k < net->layers[j].n; ++k) if (net->layers[j].input_layers[k] == i) used = 1;
+                if (net->layers[j].type == SHORTCUT && net->layers[j].index == i) used = 1;
+            }
             if (used) continue;
             ld_of(l)->fused_pool = 1;
             ld_of(m)->fused_into = i;
@@ -382,6 +384,7 @@ int y2_engine_build(network *net)
                 if (pd && pd->out_half) { y2_fail("fp16 mode: layer %d (%s) needs an fp32 producer (a convolutional or avgpool layer)", i, get_layer_string(l->type)); return -1; }
                 break;
             case COST: d->out_half = pd ? pd->out_half : 0; break;
+            case SHORTCUT: y2_fail("fp16 mode: [shortcut] (layer %d) has no half-precision kernel", i); return -1;
             default: break;
             }
         }
@@ -418,6 +421,13 @@ int y2_engine_build(network *net)
                 d->out = d->out_alloc;
                 d->out_ld = l->out_c;
             }
+            break;
+        case SHORTCUT:
+            d->out_floats = (size_t)l->batch * l->out_h * l->out_w * l->out_c;
+            HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * sizeof(float)));
+            d->out = d->out_alloc;
+            d->out_ld = l->out_c;
+            d->kernel = "shortcut";
             break;
         case ROUTE:
             d->kernel = "route(zero-copy)";
@@ -721,6 +731,15 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
             if (l->softmax_tree) { y2_fail("softmax layer with tree= is not implemented on the device"); return -1; }
             HIPCALL(y2h_softmax_rows(x, d->d_flat, (long)l->batch * l->groups, l->inputs / l->groups, l->temperature, e->stream));
         } break;
+        case SHORTCUT: {
+            const y2_ldev *fd = ld_of(&net->layers[l->index]);
+            int act = l->activation == LEAKY ? Y2H_ACT_LEAKY : l->activation == LOGISTIC ? Y2H_ACT_LOGISTIC :
+                      l->activation == RELU ? Y2H_ACT_RELU : l->activation == LINEAR ? Y2H_ACT_LINEAR : -1;
+            if (act < 0) { y2_fail("shortcut layer %d: activation %d is not implemented on the device", i, (int)l->activation); return -1; }
+            if (i == 0) { y2_fail("shortcut layer %d has no input layer", i); return -1; }
+            HIPCALL(y2h_shortcut(x, ldx, fd->out, fd->out_ld, d->out, d->out_ld, l->batch, l->w, l->h, l->c,
+                                 l->out_w, l->out_h, l->out_c, act, e->stream));
+        } break;
         case COST:
             break;                    /* cost_layer.c:75: nothing happens without truth */
         default:
@@ -1015,6 +1034,7 @@ char *get_layer_string(LAYER_TYPE a)         /* network.c:73-130 */
     case AVGPOOL: return "avgpool";
     case SOFTMAX: return "softmax";
     case COST: return "cost";
+    case SHORTCUT: return "shortcut";
     default: return "none";
     }
 }

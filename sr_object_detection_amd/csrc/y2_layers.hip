@@ -279,3 +279,49 @@ extern "C" int y2h_region_forward(const float *x, int ldx, float *y, int batch, 
     }
     return Y2H_OK;
 }
+
+// ---------------------------------------------------------------------------
+// shortcut (residual add): shortcut_layer.c:38-43 = copy input, shortcut_cpu (blas.c:57-81), activate_array.
+// `add` is the output of layer `from` (w1 x h1 x c1), the result has this layer's input shape (w2 x h2 x c2);
+// with stride = w1/w2 and sample = w2/w1 (each at least 1) element (x*sample, y*sample, k) of the result receives
+// add(x*stride, y*stride, k) for x < min(w1,w2), y < min(h1,h2), k < min(c1,c2).  One add per element, then the
+// activation in the reference's arithmetic (leaky = .1*x in double).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shortcut_kernel(const float *__restrict__ in, int ld_in, const float *__restrict__ add,
+                                                       int ld_add, float *__restrict__ out, int ld_out, int w1, int h1, int c1,
+                                                       int w2, int h2, int c2, int stride, int sample, int act, long total)
+{
+    const int minw = w1 < w2 ? w1 : w2, minh = h1 < h2 ? h1 : h2, minc = c1 < c2 ? c1 : c2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % c2);
+        const long pix = idx / c2;
+        const int x = (int)(pix % w2);
+        const int y = (int)((pix / w2) % h2);
+        const long b = pix / ((long)w2 * h2);
+        float v = in[pix * ld_in + k];
+        if (k < minc && x % sample == 0 && y % sample == 0 && x / sample < minw && y / sample < minh) {
+            const long ap = (b * h1 + (long)(y / sample) * stride) * w1 + (long)(x / sample) * stride;
+            v = v + add[ap * ld_add + k];
+        }
+        if (act == Y2H_ACT_LEAKY) v = (v > 0) ? v : (float)(.1 * (double)v);
+        else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));
+        else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);
+        out[pix * ld_out + k] = v;
+    }
+}
+
+extern "C" int y2h_shortcut(const float *in, int ld_in, const float *add, int ld_add, float *out, int ld_out, int batch,
+                            int w1, int h1, int c1, int w2, int h2, int c2, int activation, y2h_stream s)
+{
+    if (!in || !add || !out || batch <= 0 || w1 <= 0 || h1 <= 0 || c1 <= 0 || w2 <= 0 || h2 <= 0 || c2 <= 0) return Y2H_EINVAL;
+    if (ld_in < c2 || ld_out < c2 || ld_add < c1) return Y2H_EINVAL;
+    int stride = w1 / w2, sample = w2 / w1;
+    if (stride != h1 / h2 || sample != h2 / h1) return Y2H_EINVAL;      /* the reference asserts this (blas.c:61-62) */
+    if (stride < 1) stride = 1;
+    if (sample < 1) sample = 1;
+    const long total = (long)batch * h2 * w2 * c2;
+    hipLaunchKernelGGL(shortcut_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), in, ld_in, add, ld_add, out, ld_out,
+                       w1, h1, c1, w2, h2, c2, stride, sample, activation, total);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

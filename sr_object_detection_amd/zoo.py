@@ -78,7 +78,16 @@ SPECS["mini-mfma"] = [
     ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]}),
 ]
 
-DEFAULT_SIZE = {"yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64}
+# residual blocks (shortcut_layer.c): an identity shortcut, a strided conv, and a shortcut whose
+# source is twice as large and half as deep (the stride / min-channel branch of blas.c:57-81 shortcut_cpu)
+SPECS["mini-res"] = [
+    ("conv", 16, 3, 1, "leaky"), ("conv", 16, 1, 1, "leaky"), ("conv", 16, 3, 1, "linear"), ("shortcut", -3, "leaky"),
+    ("conv", 32, 3, 1, "leaky", 2), ("conv", 32, 1, 1, "linear"), ("shortcut", -3, "linear"),
+    ("conv", 32, 3, 1, "leaky"), ("shortcut", -2, "leaky"), ("conv", 30, 1, 0, "linear"),
+    ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]}),
+]
+
+DEFAULT_SIZE = {"yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32}
 
 
 def cfg_text(name: str, width: int | None = None, height: int | None = None, batch: int = 1,
@@ -91,8 +100,9 @@ def cfg_text(name: str, width: int | None = None, height: int | None = None, bat
     for e in spec:
         kind = e[0]
         if kind == "conv":
-            _, filters, size, bn, act = e
-            out += ["[convolutional]", "filters=%d" % filters, "size=%d" % size, "stride=1", "pad=1"]
+            _, filters, size, bn, act = e[:5]
+            stride = e[5] if len(e) > 5 else 1
+            out += ["[convolutional]", "filters=%d" % filters, "size=%d" % size, "stride=%d" % stride, "pad=1"]
             if bn:
                 out.append("batch_normalize=1")
             out += ["activation=%s" % act, ""]
@@ -113,6 +123,8 @@ def cfg_text(name: str, width: int | None = None, height: int | None = None, bat
             if r.get("map") and map_path:
                 out.append("map=%s" % map_path)
             out.append("")
+        elif kind == "shortcut":
+            out += ["[shortcut]", "from=%d" % e[1], "activation=%s" % e[2], ""]
         elif kind == "avg":
             out += ["[avgpool]", ""]
         elif kind == "softmax":
@@ -135,10 +147,12 @@ def resolve(name_or_spec, width: int, height: int | None = None, channels: int =
         kind = e[0]
         L = {"w": w, "h": h, "c": c, "inputs": inputs}
         if kind == "conv":
-            _, filters, size, bn, act = e
+            _, filters, size, bn, act = e[:5]
+            stride = e[5] if len(e) > 5 else 1
             pad = size // 2
-            L.update(type="convolutional", filters=filters, size=size, stride=1, pad=pad, batch_normalize=bn,
-                     activation=act, out_w=(w + 2 * pad - size) + 1, out_h=(h + 2 * pad - size) + 1, out_c=filters)
+            L.update(type="convolutional", filters=filters, size=size, stride=stride, pad=pad, batch_normalize=bn,
+                     activation=act, out_w=(w + 2 * pad - size) // stride + 1, out_h=(h + 2 * pad - size) // stride + 1,
+                     out_c=filters)
         elif kind == "max":
             size, stride = e[1], e[2]
             pad = (size - 1) // 2
@@ -156,6 +170,8 @@ def resolve(name_or_spec, width: int, height: int | None = None, channels: int =
             r = e[1]
             L.update(type="region", classes=r["classes"], coords=4, num=r["num"], anchors=r["anchors"],
                      out_w=0, out_h=0, out_c=0, outputs=w * h * r["num"] * (r["classes"] + 5))
+        elif kind == "shortcut":
+            L.update(type="shortcut", index=i + e[1] if e[1] < 0 else e[1], activation=e[2], out_w=w, out_h=h, out_c=c)
         elif kind == "avg":
             L.update(type="avgpool", out_w=1, out_h=1, out_c=c)
         elif kind in ("softmax", "cost"):

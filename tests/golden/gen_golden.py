@@ -46,6 +46,7 @@ CASES = [
     ("darknet19_224_b1", "darknet19", 224, 1, 41, 0.0, 0.0, 1.0),
     ("yolo9000_96_b1", "yolo9000", 96, 1, 51, 0.2, 0.4, 4.0),
     ("yolo9000_96_b1_map", "yolo9000", 96, 1, 51, 0.2, 0.4, 4.0),
+    ("mini_res_32_b2", "mini-res", 32, 2, 61, 0.5, 0.4, 4.0),      # [shortcut] + a stride-2 convolution
 ]
 
 

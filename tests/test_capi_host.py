@@ -60,7 +60,7 @@ def table_of(net):
     return rows
 
 
-@pytest.mark.parametrize("name,size,batch", [("mini", 32, 2), ("mini-mfma", 64, 2), ("tiny-yolo-voc", 416, 1),
+@pytest.mark.parametrize("name,size,batch", [("mini", 32, 2), ("mini-mfma", 64, 2), ("mini-res", 32, 2), ("tiny-yolo-voc", 416, 1),
                                              ("yolo", 608, 4), ("darknet19", 448, 2), ("yolo9000", 544, 1)])
 def test_cfg_parse_matches_oracle_and_zoo(oracle, workdir, name, size, batch):
     cfg, _, _ = materialize(workdir, name, size, batch, 1) if name in ("mini", "mini-mfma") else (None, None, None)
@@ -209,3 +209,19 @@ def test_denormalize_net_writes_the_reference_weight_file(workdir):
     net.save_weights(out)
     assert open(out, "rb").read() == bytes(g["weights"])
     net.free()
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_ROOT), reason="reference checkout not present (GPU box)")
+def test_reference_resnet50_cfg_parses(oracle):
+    """cfg/resnet50.cfg ([shortcut] + strided convolutions) is accepted verbatim; shapes agree with the oracle"""
+    path = os.path.join(REFERENCE_ROOT, "cfg", "resnet50.cfg")
+    net = darknet.Network.parse_network_cfg(path)
+    on = oracle.OracleNet(path)
+    assert net.n == on.n == 70 and net.output_size == 1000
+    rows = table_of(net)
+    assert sum(r["type"] == "shortcut" for r in rows) == 16
+    for i, row in enumerate(rows):
+        o = on.layer_info(i)
+        assert row["type"] == o["type"] and row["outputs"] == o["outputs"], i
+    net.free()
+    on.close()

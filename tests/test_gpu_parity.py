@@ -21,7 +21,7 @@ def boxes_close(got, want):
     scale = np.maximum(1.0, np.abs(want))
     return bool((np.abs(got - want) < TOL * scale).all())
 
-CASES = ["mini_32_b2", "mini_64_b3", "mini_mfma_64_b2", "tiny_yolo_voc_416_b1", "tiny_yolo_voc_416_b1_kinect",
+CASES = ["mini_32_b2", "mini_64_b3", "mini_mfma_64_b2", "mini_res_32_b2", "tiny_yolo_voc_416_b1", "tiny_yolo_voc_416_b1_kinect",
          "yolo_416_b1", "yolo_608_b1"]
 
 
@@ -82,7 +82,7 @@ def test_decode_and_nms_match_reference_golden(workdir, name):
     net.free()
 
 
-@pytest.mark.parametrize("name", ["mini_32_b2", "mini_mfma_64_b2", "tiny_yolo_voc_416_b1"])
+@pytest.mark.parametrize("name", ["mini_32_b2", "mini_mfma_64_b2", "mini_res_32_b2", "tiny_yolo_voc_416_b1"])
 def test_strict_mode_is_bit_identical_to_reference(workdir, name):
     """With the reference-order VALU convolution every layer, the decode and the NMS are bit-exact."""
     g, net, x, out, thresh, nms = run_case(workdir, name, strict=True)
