@@ -126,6 +126,9 @@ struct layer {
     float *cost;
     size_t workspace_size;                /* the reference's im2col bytes (convolutional_layer.c:135); informational */
     void *dev;                            /* opaque device-side state */
+    /* YOLOv1 family: [detection] grid side and `forced`, [dropout] probability */
+    int side, forced;
+    float probability;
 };
 
 /* network.h:19-67, forward-path subset */

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liby2oracle.so")
 REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
 
-KINDS = ["convolutional", "maxpool", "route", "reorg", "region", "avgpool", "softmax", "cost", "shortcut"]
+KINDS = ["convolutional", "maxpool", "route", "reorg", "region", "avgpool", "softmax", "cost", "shortcut", "connected", "dropout",
+         "detection"]
 
 
 def build(force: bool = False) -> str:
@@ -133,6 +134,17 @@ class OracleNet:
         probs = np.zeros((total, info["classes"]), dtype=np.float32)
         boxes = np.zeros((total, 4), dtype=np.float32)
         self.L.orc_get_region_boxes(self.h, self.last, b, w, h, thresh, _p(probs), _p(boxes), only_objectness, use_map)
+        return boxes, probs
+
+    def detection_boxes(self, b: int, thresh: float, w: int = 1, h: int = 1, only_objectness: int = 0):
+        """YOLOv1 head decode (src_yolo2/detection_layer.c:222 get_detection_boxes) of batch item b."""
+        info = self.layer_info(self.last)
+        assert info["type"] == "detection"
+        total = info["w"] * info["h"] * info["n"]
+        probs = np.zeros((total, info["classes"]), dtype=np.float32)
+        boxes = np.zeros((total, 4), dtype=np.float32)
+        self.L.orc_get_detection_boxes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        assert self.L.orc_get_detection_boxes(self.h, b, w, h, thresh, only_objectness, _p(boxes), _p(probs)) == 0
         return boxes, probs
 
     def time_predict(self, x: np.ndarray, iters: int) -> float:

@@ -27,6 +27,7 @@
 #include "network.h"
 #include "parser.h"
 #include "region_layer.h"
+#include "detection_layer.h"
 #include "box.h"
 #include "blas.h"
 #include "utils.h"
@@ -136,6 +137,29 @@ static int cmd_net(int argc, char **argv)
             snprintf(nm, sizeof nm, "probs_pre_%d.bin", b);
             write_raw(outdir, nm, flat, (size_t)total * ncls * sizeof(float));
             if (nms > 0) do_nms_sort(boxes, probs, total, out_cls, nms);
+            snprintf(nm, sizeof nm, "probs_post_%d.bin", b);
+            write_raw(outdir, nm, flat, (size_t)total * ncls * sizeof(float));
+        }
+        free(boxes); free(probs); free(flat);
+    }
+    if (l.type == DETECTION) {      /* YOLOv1 head: yolo.c:324-325 get_detection_boxes(l,1,1,thresh,..,0) + do_nms_sort */
+        int total = l.side * l.side * l.n, b, j;
+        int ncls = l.classes;
+        box *boxes = calloc(total, sizeof(box));
+        float **probs = calloc(total, sizeof(float *));
+        float *flat = calloc((size_t)total * ncls, sizeof(float));
+        for (j = 0; j < total; ++j) probs[j] = flat + (size_t)j * ncls;
+        for (b = 0; b < net.batch; ++b) {
+            layer lb = l;
+            char nm[64];
+            lb.output = l.output + (size_t)b * l.outputs;
+            memset(flat, 0, (size_t)total * ncls * sizeof(float));
+            get_detection_boxes(lb, 1, 1, thresh, probs, boxes, 0);
+            snprintf(nm, sizeof nm, "boxes_%d.bin", b);
+            write_raw(outdir, nm, boxes, total * sizeof(box));
+            snprintf(nm, sizeof nm, "probs_pre_%d.bin", b);
+            write_raw(outdir, nm, flat, (size_t)total * ncls * sizeof(float));
+            if (nms > 0) do_nms_sort(boxes, probs, total, ncls, nms);
             snprintf(nm, sizeof nm, "probs_post_%d.bin", b);
             write_raw(outdir, nm, flat, (size_t)total * ncls * sizeof(float));
         }

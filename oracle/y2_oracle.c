@@ -28,7 +28,8 @@
 #include <stdint.h>
 #include <time.h>
 
-enum { ORC_CONV = 0, ORC_MAXPOOL, ORC_ROUTE, ORC_REORG, ORC_REGION, ORC_AVGPOOL, ORC_SOFTMAX, ORC_COST, ORC_SHORTCUT };
+enum { ORC_CONV = 0, ORC_MAXPOOL, ORC_ROUTE, ORC_REORG, ORC_REGION, ORC_AVGPOOL, ORC_SOFTMAX, ORC_COST, ORC_SHORTCUT,
+       ORC_CONNECTED, ORC_DROPOUT, ORC_DETECTION };
 enum { ACT_LOGISTIC = 0, ACT_RELU, ACT_LINEAR, ACT_LEAKY, ACT_RAMP, ACT_TANH, ACT_ELU, ACT_HARDTAN };
 
 typedef struct {
@@ -52,6 +53,7 @@ typedef struct {
     int batch_normalize, activation, flipped;
     int reverse;
     int classes, coords, softmax, classfix;
+    int side, sqrt_;   /* [detection] */
     int groups;
     float temperature;
     int dontload, dontloadscales;
@@ -397,6 +399,42 @@ orc_net *orc_parse_cfg(const char *path)
             /* parser.c:309-317, cost_layer.c:32-55: no-op at inference (cost_layer.c:75) */
             l->kind = ORC_COST;
             l->inputs = inputs; l->outputs = inputs;
+        } else if (!strcmp(t, "[connected]") || !strcmp(t, "[conn]")) {
+            /* parser.c:214-224, connected_layer.c:13-89 */
+            int k;
+            l->kind = ORC_CONNECTED;
+            l->outputs = opt_int(s, "output", 1);
+            l->activation = activation_from_name(opt(s, "activation") ? opt(s, "activation") : "logistic");
+            l->batch_normalize = opt_int(s, "batch_normalize", 0);
+            l->inputs = inputs;
+            l->h = 1; l->w = 1; l->c = inputs;
+            l->out_h = 1; l->out_w = 1; l->out_c = l->outputs;
+            l->n = l->outputs;
+            l->weights = calloc((size_t)l->outputs * inputs, sizeof(float));
+            l->biases = calloc(l->outputs, sizeof(float));
+            if (l->batch_normalize) {
+                l->scales = calloc(l->outputs, sizeof(float));
+                for (k = 0; k < l->outputs; ++k) l->scales[k] = 1;
+                l->rolling_mean = calloc(l->outputs, sizeof(float));
+                l->rolling_variance = calloc(l->outputs, sizeof(float));
+            }
+        } else if (!strcmp(t, "[dropout]")) {
+            /* parser.c:389-397,658-661: at inference the layer's output IS the previous layer's output */
+            l->kind = ORC_DROPOUT;
+            l->inputs = l->outputs = inputs;
+            l->h = l->out_h = h; l->w = l->out_w = w; l->c = l->out_c = c;
+        } else if (!strcmp(t, "[detection]")) {
+            /* parser.c:285-307, detection_layer.c:14-46 */
+            l->kind = ORC_DETECTION;
+            l->coords = opt_int(s, "coords", 1);
+            l->classes = opt_int(s, "classes", 1);
+            l->n = opt_int(s, "num", 1);
+            l->side = opt_int(s, "side", 7);
+            l->softmax = opt_int(s, "softmax", 0);
+            l->sqrt_ = opt_int(s, "sqrt", 0);
+            l->inputs = l->outputs = inputs;
+            l->w = l->h = l->side;
+            if (l->side * l->side * ((1 + l->coords) * l->n + l->classes) != inputs) { fprintf(stderr, "oracle: detection layer size mismatch\n"); return NULL; }
         } else if (!strcmp(t, "[shortcut]")) {
             /* parser.c:415-430, shortcut_layer.c:7-36: l.w/h/c = the `from` layer's output shape, out = this input's */
             const char *fs = opt(s, "from");
@@ -417,7 +455,8 @@ orc_net *orc_parse_cfg(const char *path)
         }
         l->dontload = opt_int(s, "dontload", 0);
         l->dontloadscales = opt_int(s, "dontloadscales", 0);
-        l->output = calloc((size_t)l->outputs * batch > 0 ? (size_t)l->outputs * batch : 1, sizeof(float));
+        if (l->kind == ORC_DROPOUT && i > 0) l->output = net->layers[i - 1].output;      /* parser.c:660 */
+        else l->output = calloc((size_t)l->outputs * batch > 0 ? (size_t)l->outputs * batch : 1, sizeof(float));
         h = l->out_h; w = l->out_w; c = l->out_c; inputs = l->outputs;
     }
     free_sections(secs);
@@ -433,7 +472,8 @@ void orc_free_net(orc_net *net)
     for (i = 0; i < net->n; ++i) {
         orc_layer *l = &net->layers[i];
         free(l->weights); free(l->biases); free(l->scales); free(l->rolling_mean); free(l->rolling_variance);
-        free(l->output); free(l->input_layers); free(l->input_sizes); free(l->map);
+        if (l->kind != ORC_DROPOUT) free(l->output);      /* a dropout layer's output is the previous layer's */
+        free(l->input_layers); free(l->input_sizes); free(l->map);
         if (l->tree) { free(l->tree->parent); free(l->tree->group); free(l->tree->leaf); free(l->tree->group_size); free(l->tree->group_offset); free(l->tree); }
     }
     free(net->layers);
@@ -457,7 +497,18 @@ int orc_load_weights(orc_net *net, const char *path)
     for (i = 0; i < net->n; ++i) {
         orc_layer *l = &net->layers[i];
         size_t num, got = 0;
-        if (l->dontload || l->kind != ORC_CONV) continue;
+        if (l->dontload) continue;
+        if (l->kind == ORC_CONNECTED) {          /* parser.c:897-913 (the transpose flag of :1035 applies to v>1000 files only) */
+            got += fread(l->biases, sizeof(float), l->outputs, fp);
+            got += fread(l->weights, sizeof(float), (size_t)l->outputs * l->inputs, fp);
+            if (l->batch_normalize && !l->dontloadscales) {
+                got += fread(l->scales, sizeof(float), l->outputs, fp);
+                got += fread(l->rolling_mean, sizeof(float), l->outputs, fp);
+                got += fread(l->rolling_variance, sizeof(float), l->outputs, fp);
+            }
+            continue;
+        }
+        if (l->kind != ORC_CONV) continue;
         num = (size_t)l->n * l->c * l->size * l->size;
         got += fread(l->biases, sizeof(float), l->n, fp);
         if (l->batch_normalize && !l->dontloadscales) {
@@ -724,6 +775,36 @@ float *orc_predict(orc_net *net, const float *input)
         case ORC_AVGPOOL: forward_avgpool(l, cur); break;
         case ORC_SOFTMAX: forward_softmax(l, cur); break;
         case ORC_COST: break;      /* cost_layer.c:75: returns at once without truth */
+        case ORC_DROPOUT: break;   /* dropout_layer.c:34: returns at once unless training; output aliases the input */
+        case ORC_CONNECTED: {      /* connected_layer.c:141-176: gemm(0,1,...) = gemm_nt (gemm.c:90-106), BN, bias, activation */
+            int o, kk, m = l->batch, n = l->outputs, kdim = l->inputs;
+            size_t e;
+#pragma omp parallel for collapse(2) private(kk)
+            for (b = 0; b < m; ++b) for (o = 0; o < n; ++o) {
+                float sum = 0;
+                const float *ar = cur + (size_t)b * kdim, *br = l->weights + (size_t)o * kdim;
+                for (kk = 0; kk < kdim; ++kk) sum += ar[kk] * br[kk];
+                l->output[(size_t)b * n + o] = 0 + sum;
+            }
+            if (l->batch_normalize) {          /* normalize_cpu blas.c:115-126 with spatial 1, scale_bias */
+                for (b = 0; b < m; ++b) for (o = 0; o < n; ++o) {
+                    size_t idx = (size_t)b * n + o;
+                    l->output[idx] = (l->output[idx] - l->rolling_mean[o]) / (sqrt(l->rolling_variance[o]) + .000001f);
+                }
+                for (b = 0; b < m; ++b) for (o = 0; o < n; ++o) l->output[(size_t)b * n + o] *= l->scales[o];
+            }
+            for (b = 0; b < m; ++b) for (o = 0; o < n; ++o) l->output[(size_t)b * n + o] += l->biases[o];
+            for (e = 0; e < (size_t)m * n; ++e) l->output[e] = act(l->output[e], l->activation);
+        } break;
+        case ORC_DETECTION: {      /* detection_layer.c:49-66 (inference part): copy, per-cell class softmax */
+            int locations = l->side * l->side, loc;
+            memcpy(l->output, cur, (size_t)l->outputs * l->batch * sizeof(float));
+            if (l->softmax)
+                for (b = 0; b < l->batch; ++b) for (loc = 0; loc < locations; ++loc) {
+                    float *pc = l->output + (size_t)b * l->inputs + (size_t)loc * l->classes;
+                    orc_softmax(pc, l->classes, 1, pc);
+                }
+        } break;
         case ORC_SHORTCUT: {       /* shortcut_layer.c:38-43: copy, shortcut_cpu (blas.c:57-81), activate_array */
             const float *add = net->layers[l->n].output;
             const int w1 = l->w, h1 = l->h, c1 = l->c, w2 = l->out_w, h2 = l->out_h, c2 = l->out_c;
@@ -1092,6 +1173,37 @@ int orc_write_detections(int kind, const char **paths, const char *id, int numer
     }
     for (j = 0; j < nf; ++j) fclose(fps[j]);
     free(fps);
+    return 0;
+}
+
+int orc_last_layer(const orc_net *net);
+/* detection_layer.c:222-251 get_detection_boxes on batch item b of the network's last layer */
+int orc_get_detection_boxes(orc_net *net, int b, int w, int h, float thresh, int only_objectness, float *boxes, float *probs)
+{
+    orc_layer *l = &net->layers[orc_last_layer(net)];
+    const float *predictions;
+    int i, j, n;
+    if (l->kind != ORC_DETECTION) return -1;
+    predictions = l->output + (size_t)b * l->outputs;
+    for (i = 0; i < l->side * l->side; ++i) {
+        int row = i / l->side, col = i % l->side;
+        for (n = 0; n < l->n; ++n) {
+            int index = i * l->n + n;
+            int p_index = l->side * l->side * l->classes + i * l->n + n;
+            float scale = predictions[p_index];
+            int box_index = l->side * l->side * (l->classes + l->n) + (i * l->n + n) * 4;
+            boxes[index * 4 + 0] = (predictions[box_index + 0] + col) / l->side * w;
+            boxes[index * 4 + 1] = (predictions[box_index + 1] + row) / l->side * h;
+            boxes[index * 4 + 2] = pow(predictions[box_index + 2], (l->sqrt_ ? 2 : 1)) * w;
+            boxes[index * 4 + 3] = pow(predictions[box_index + 3], (l->sqrt_ ? 2 : 1)) * h;
+            for (j = 0; j < l->classes; ++j) {
+                int class_index = i * l->classes;
+                float prob = scale * predictions[class_index + j];
+                probs[(size_t)index * l->classes + j] = (prob > thresh) ? prob : 0;
+            }
+            if (only_objectness) probs[(size_t)index * l->classes] = scale;
+        }
+    }
     return 0;
 }
 

@@ -453,6 +453,79 @@ static layer make_route(list *o, shape p, network *net)
     return l;
 }
 
+/* parser.c:214-224 parse_connected + connected_layer.c:13-89: a dense layer on the flattened input; weights
+ * [outputs][inputs] (row = one output), optional batch-norm over the outputs */
+static layer make_connected(list *o, shape p)
+{
+    layer l;
+    int i;
+    memset(&l, 0, sizeof l);
+    l.type = CONNECTED;
+    l.outputs = option_find_int(o, "output", 1);
+    l.activation = activation_by_name(option_find_str(o, "activation", "logistic"));
+    l.batch_normalize = option_find_int_quiet(o, "batch_normalize", 0);
+    if (p.inputs <= 0 || l.outputs <= 0) { y2_fail("bad connected layer geometry"); return l; }
+    l.inputs = p.inputs;
+    l.batch = p.batch;
+    l.h = 1; l.w = 1; l.c = l.inputs;
+    l.out_h = 1; l.out_w = 1; l.out_c = l.outputs;
+    l.n = l.outputs; l.size = 1; l.stride = 1; l.pad = 0;        /* = a 1x1 convolution over a 1x1 image */
+    l.weights = calloc((size_t)l.outputs * l.inputs, sizeof(float));
+    l.biases = calloc(l.outputs, sizeof(float));
+    if (l.batch_normalize) {
+        l.scales = calloc(l.outputs, sizeof(float));
+        for (i = 0; i < l.outputs; ++i) l.scales[i] = 1;
+        l.rolling_mean = calloc(l.outputs, sizeof(float));
+        l.rolling_variance = calloc(l.outputs, sizeof(float));
+    }
+    fprintf(stderr, "connected                            %4d  ->  %4d\n", l.inputs, l.outputs);
+    return l;
+}
+
+/* parser.c:389-397: at inference a no-op whose output IS the previous layer's (parser.c:658-661) */
+static layer make_dropout(list *o, shape p)
+{
+    layer l;
+    memset(&l, 0, sizeof l);
+    l.type = DROPOUT;
+    l.probability = option_find_float(o, "probability", .5f);
+    l.inputs = l.outputs = p.inputs;
+    l.batch = p.batch;
+    l.h = l.out_h = p.h; l.w = l.out_w = p.w; l.c = l.out_c = p.c;
+    fprintf(stderr, "dropout       p = %.2f               %4d  ->  %4d\n", l.probability, l.inputs, l.inputs);
+    return l;
+}
+
+/* parser.c:285-307 parse_detection + detection_layer.c:14-46 (YOLOv1 head) */
+static layer make_detection(list *o, shape p)
+{
+    static const char *const quiet[] = { "coord_scale", "object_scale", "noobject_scale", "class_scale", "jitter", "random",
+                                         "reorg", "max", 0 };
+    layer l;
+    memset(&l, 0, sizeof l);
+    l.type = DETECTION;
+    l.coords = option_find_int(o, "coords", 1);
+    l.classes = option_find_int(o, "classes", 1);
+    l.rescore = option_find_int(o, "rescore", 0);
+    l.n = option_find_int(o, "num", 1);
+    l.side = option_find_int(o, "side", 7);
+    l.softmax = option_find_int(o, "softmax", 0);
+    l.sqrt = option_find_int(o, "sqrt", 0);
+    l.forced = option_find_int(o, "forced", 0);
+    touch(o, quiet);
+    l.batch = p.batch;
+    l.inputs = l.outputs = p.inputs;
+    l.w = l.h = l.side;
+    if (l.side * l.side * ((1 + l.coords) * l.n + l.classes) != p.inputs) {     /* detection_layer.c:27 asserts this */
+        y2_fail("detection layer: side*side*((1+coords)*num+classes) = %d but the input has %d values",
+                l.side * l.side * ((1 + l.coords) * l.n + l.classes), p.inputs);
+        return l;
+    }
+    l.truths = l.side * l.side * (1 + l.coords + l.classes);
+    fprintf(stderr, "Detection Layer\n");
+    return l;
+}
+
 /* parser.c:415-430 parse_shortcut + shortcut_layer.c:7-36: l.w/h/c = shape of the `from` layer's output,
  * out = this layer's input shape, l.index = the `from` layer (the reference's field of that name) */
 static layer make_shortcut(list *o, shape p, network *net)
@@ -676,6 +749,9 @@ network parse_network_cfg(char *filename)    /* parser.c:585-700 */
         else if (is_type(t, "[route]", NULL)) l = make_route(s->options, p, &net);
         else if (is_type(t, "[reorg]", NULL)) l = make_reorg(s->options, p);
         else if (is_type(t, "[shortcut]", NULL)) l = make_shortcut(s->options, p, &net);
+        else if (is_type(t, "[connected]", "[conn]")) l = make_connected(s->options, p);
+        else if (is_type(t, "[dropout]", NULL)) l = make_dropout(s->options, p);
+        else if (is_type(t, "[detection]", NULL)) l = make_detection(s->options, p);
         else if (is_type(t, "[region]", NULL)) l = make_region(s->options, p);
         else if (is_type(t, "[avgpool]", "[avg]")) l = make_avgpool(p);
         else if (is_type(t, "[softmax]", "[soft]")) { l = make_softmax(s->options, p); net.hierarchy = l.softmax_tree; }

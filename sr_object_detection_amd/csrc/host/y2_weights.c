@@ -55,7 +55,20 @@ void load_weights_upto(network *net, char *filename, int cutoff)
     for (i = 0; i < net->n && i < cutoff; ++i) {
         layer *l = &net->layers[i];
         size_t num;
-        if (l->dontload || l->type != CONVOLUTIONAL) continue;
+        if (l->dontload) continue;
+        if (l->type == CONNECTED) {                  /* parser.c:897-913 load_connected_weights */
+            num = (size_t)l->outputs * l->inputs;
+            if (fread(l->biases, sizeof(float), l->outputs, fp) != (size_t)l->outputs) break;
+            if (fread(l->weights, sizeof(float), num, fp) != num) break;
+            if (major > 1000 || minor > 1000) transpose_in_place(l->weights, l->inputs, l->outputs);   /* parser.c:1035 */
+            if (l->batch_normalize && !l->dontloadscales) {
+                if (fread(l->scales, sizeof(float), l->outputs, fp) != (size_t)l->outputs) break;
+                if (fread(l->rolling_mean, sizeof(float), l->outputs, fp) != (size_t)l->outputs) break;
+                if (fread(l->rolling_variance, sizeof(float), l->outputs, fp) != (size_t)l->outputs) break;
+            }
+            continue;
+        }
+        if (l->type != CONVOLUTIONAL) continue;
         num = (size_t)l->n * l->c * l->size * l->size;
         /* short reads leave the remaining values untouched, as in the reference */
         if (fread(l->biases, sizeof(float), l->n, fp) != (size_t)l->n) break;
@@ -89,6 +102,16 @@ void save_weights_upto(network net, char *filename, int cutoff)
     fwrite(hdr, 4, 4, fp);
     for (i = 0; i < net.n && i < cutoff; ++i) {
         layer *l = &net.layers[i];
+        if (l->type == CONNECTED) {                  /* parser.c:806-820 save_connected_weights */
+            fwrite(l->biases, sizeof(float), l->outputs, fp);
+            fwrite(l->weights, sizeof(float), (size_t)l->outputs * l->inputs, fp);
+            if (l->batch_normalize) {
+                fwrite(l->scales, sizeof(float), l->outputs, fp);
+                fwrite(l->rolling_mean, sizeof(float), l->outputs, fp);
+                fwrite(l->rolling_variance, sizeof(float), l->outputs, fp);
+            }
+            continue;
+        }
         if (l->type != CONVOLUTIONAL) continue;
         fwrite(l->biases, sizeof(float), l->n, fp);
         if (l->batch_normalize) {

@@ -75,6 +75,7 @@ class Layer(C.Structure):    # include/sr_yolo2.h struct layer
         ("rolling_mean", C.POINTER(C.c_float)), ("rolling_variance", C.POINTER(C.c_float)),
         ("output", C.POINTER(C.c_float)), ("delta", C.POINTER(C.c_float)), ("cost", C.POINTER(C.c_float)),
         ("workspace_size", C.c_size_t), ("dev", C.c_void_p),
+        ("side", C.c_int), ("forced", C.c_int), ("probability", C.c_float),
     ]
 
 

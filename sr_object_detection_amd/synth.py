@@ -97,13 +97,28 @@ def write_weights(path: str, layers, seed: int, head_gain: float = 4.0, version=
             f.write(struct.pack("<Q", 0))
         else:
             f.write(struct.pack("<i", 0))
-        for p in conv_params(layers, seed, head_gain):
-            f.write(p["biases"].tobytes())
-            if "scales" in p:
-                f.write(p["scales"].tobytes())
-                f.write(p["rolling_mean"].tobytes())
-                f.write(p["rolling_variance"].tobytes())
-            f.write(p["weights"].tobytes())
+        convs = conv_params(layers, seed, head_gain)
+        for li, l in enumerate(layers):
+            if l["type"] == "convolutional":
+                p = next(convs)
+                f.write(p["biases"].tobytes())
+                if "scales" in p:
+                    f.write(p["scales"].tobytes())
+                    f.write(p["rolling_mean"].tobytes())
+                    f.write(p["rolling_variance"].tobytes())
+                f.write(p["weights"].tobytes())
+            elif l["type"] == "connected":
+                # parser.c:806-820 order: biases, weights [outputs][inputs], then scales / mean / variance
+                n, K = l["outputs"], l["inputs"]
+                s = seed * 1000003 + 500000 + li * 7919
+                head = li + 1 < len(layers) and layers[li + 1]["type"] == "detection"
+                a = math.sqrt(6.0 / K) * (0.5 if head else 1.0)
+                f.write((uniform(s + 1, n, 0.2, 0.8) if head else uniform(s + 1, n, -0.1, 0.1)).tobytes())
+                f.write(uniform(s + 5, n * K, -a, a).tobytes())
+                if l.get("batch_normalize"):
+                    f.write(uniform(s + 2, n, 0.8, 1.2).tobytes())
+                    f.write(uniform(s + 3, n, -0.1, 0.1).tobytes())
+                    f.write(uniform(s + 4, n, 0.5, 1.5).tobytes())
         return f.tell()
 
 

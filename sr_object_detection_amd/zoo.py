@@ -87,7 +87,23 @@ SPECS["mini-res"] = [
     ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]}),
 ]
 
-DEFAULT_SIZE = {"yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32}
+# YOLOv1 family: cfg/yolov1/tiny-yolo.cfg -- convolutions, one dense layer, the [detection] head
+SPECS["tiny-yolo-v1"] = [
+    ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("conv", 32, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 64, 3, 1, "leaky"), ("max", 2, 2), ("conv", 128, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 256, 3, 1, "leaky"), ("max", 2, 2), ("conv", 512, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 1024, 3, 1, "leaky"), ("conv", 256, 3, 1, "leaky"), ("connected", 1470, 0, "linear"),
+    ("detection", {"classes": 20, "num": 2, "side": 7, "softmax": 0, "sqrt": 1}),
+]
+# small version for tests: a dense layer on an image (weights re-ordered for NHWC), dropout, a dense layer with
+# batch-norm on a vector, softmax classes
+SPECS["mini-v1"] = [
+    ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("conv", 32, 3, 1, "leaky"), ("max", 2, 2),
+    ("connected", 96, 1, "leaky"), ("dropout", 0.5), ("connected", 240, 0, "linear"),
+    ("detection", {"classes": 5, "num": 2, "side": 4, "softmax": 1, "sqrt": 1}),
+]
+
+DEFAULT_SIZE = {"yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32, "tiny-yolo-v1": 448, "mini-v1": 32}
 
 
 def cfg_text(name: str, width: int | None = None, height: int | None = None, batch: int = 1,
@@ -125,6 +141,14 @@ def cfg_text(name: str, width: int | None = None, height: int | None = None, bat
             out.append("")
         elif kind == "shortcut":
             out += ["[shortcut]", "from=%d" % e[1], "activation=%s" % e[2], ""]
+        elif kind == "connected":
+            out += ["[connected]", "output=%d" % e[1]] + (["batch_normalize=1"] if e[2] else []) + ["activation=%s" % e[3], ""]
+        elif kind == "dropout":
+            out += ["[dropout]", "probability=%g" % e[1], ""]
+        elif kind == "detection":
+            d = e[1]
+            out += ["[detection]", "classes=%d" % d["classes"], "coords=4", "rescore=1", "side=%d" % d["side"],
+                    "num=%d" % d["num"], "softmax=%d" % d.get("softmax", 0), "sqrt=%d" % d.get("sqrt", 1), "jitter=.2", ""]
         elif kind == "avg":
             out += ["[avgpool]", ""]
         elif kind == "softmax":
@@ -172,6 +196,14 @@ def resolve(name_or_spec, width: int, height: int | None = None, channels: int =
                      out_w=0, out_h=0, out_c=0, outputs=w * h * r["num"] * (r["classes"] + 5))
         elif kind == "shortcut":
             L.update(type="shortcut", index=i + e[1] if e[1] < 0 else e[1], activation=e[2], out_w=w, out_h=h, out_c=c)
+        elif kind == "connected":
+            L.update(type="connected", outputs=e[1], batch_normalize=e[2], activation=e[3], out_w=1, out_h=1, out_c=e[1])
+        elif kind == "dropout":
+            L.update(type="dropout", out_w=w, out_h=h, out_c=c, outputs=inputs)
+        elif kind == "detection":
+            d = e[1]
+            L.update(type="detection", classes=d["classes"], num=d["num"], side=d["side"], softmax=d.get("softmax", 0),
+                     sqrt=d.get("sqrt", 1), out_w=0, out_h=0, out_c=0, outputs=inputs)
         elif kind == "avg":
             L.update(type="avgpool", out_w=1, out_h=1, out_c=c)
         elif kind in ("softmax", "cost"):

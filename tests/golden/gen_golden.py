@@ -47,6 +47,8 @@ CASES = [
     ("yolo9000_96_b1", "yolo9000", 96, 1, 51, 0.2, 0.4, 4.0),
     ("yolo9000_96_b1_map", "yolo9000", 96, 1, 51, 0.2, 0.4, 4.0),
     ("mini_res_32_b2", "mini-res", 32, 2, 61, 0.5, 0.4, 4.0),      # [shortcut] + a stride-2 convolution
+    ("mini_v1_32_b2", "mini-v1", 32, 2, 71, 0.2, 0.4, 1.0),        # YOLOv1 head: [connected] [dropout] [detection]
+    ("tiny_yolo_v1_448_b1", "tiny-yolo-v1", 448, 1, 81, 0.2, 0.4, 1.0),
 ]
 
 
@@ -145,8 +147,8 @@ def generate_case(name, net, size, batch, seed, thresh, nms, gain, use_map):
             if use_map:                        # same forward tensor as the non-map case: keep the fixture small
                 fix["out"] = out[:0]
                 fix["out_sum"] = np.float64(out.astype(np.float64).sum())
-            if meta["last_type"] == 21:       # REGION in the reference's LAYER_TYPE enum (layer.h:33)
-                total = meta["lw"] * meta["lh"] * meta["ln"]
+            if meta["last_type"] in (21, 5):  # REGION / DETECTION in the reference's LAYER_TYPE enum (layer.h:33)
+                total = meta["lw"] * meta["lh"] * meta["ln"]      # (a detection layer has w = h = side)
                 ncls = meta["classes"]
                 for b in range(batch):
                     boxes = np.fromfile(os.path.join(tmp, "boxes_%d.bin" % b), dtype=np.float32).reshape(total, 4)

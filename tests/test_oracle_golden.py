@@ -7,7 +7,7 @@ import pytest
 
 from tests.helpers import dense_from_sparse, load_golden, materialize
 
-FAST = ["mini_32_b2", "mini_64_b3", "mini_mfma_64_b2", "mini_res_32_b2", "tiny_yolo_voc_416_b1", "tiny_yolo_voc_416_b1_kinect", "darknet19_224_b1"]
+FAST = ["mini_32_b2", "mini_64_b3", "mini_mfma_64_b2", "mini_res_32_b2", "mini_v1_32_b2", "tiny_yolo_v1_448_b1", "tiny_yolo_voc_416_b1", "tiny_yolo_voc_416_b1_kinect", "darknet19_224_b1"]
 SLOW = ["yolo_416_b1", "yolo_608_b1", "yolo9000_96_b1", "yolo9000_96_b1_map"]
 
 
@@ -36,9 +36,10 @@ def check_case(oracle, workdir, name):
         np.testing.assert_allclose(o.sum(), stats[i, 12], rtol=1e-8, atol=1e-6)
         assert float(o.min()) == pytest.approx(stats[i, 14], rel=1e-7, abs=1e-30)
         assert float(o.max()) == pytest.approx(stats[i, 15], rel=1e-7, abs=1e-30)
-    if on.layer_info(on.last)["type"] == "region":
+    head = on.layer_info(on.last)["type"]
+    if head in ("region", "detection"):
         for b in range(batch):
-            boxes, probs = on.region_boxes(b, thresh, use_map=use_map)
+            boxes, probs = on.region_boxes(b, thresh, use_map=use_map) if head == "region" else on.detection_boxes(b, thresh)
             assert np.array_equal(boxes, g["boxes_%d" % b])
             total, classes = probs.shape
             pre = dense_from_sparse(g["pre_idx_%d" % b], g["pre_val_%d" % b], total, classes)
