@@ -190,6 +190,7 @@ char *get_layer_string(LAYER_TYPE a);                            /* network.c:73
 
 /* ---- region head hand-off (region_layer.h:12, box.h:13-17) ---- */
 void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *boxes, int only_objectness, int *map);
+void get_detection_boxes(layer l, int w, int h, float thresh, float **probs, box *boxes, int only_objectness);   /* detection_layer.c:222 (YOLOv1 head) */
 void do_nms_sort(box *boxes, float **probs, int total, int classes, float thresh);   /* box.c:249 */
 void do_nms(box *boxes, float **probs, int total, int classes, float thresh);        /* box.c:279 */
 float box_iou(box a, box b);                                                         /* box.c:94  */

@@ -143,6 +143,16 @@ int y2h_maxpool(const float *x, int ldx, float *y, int ldy, int batch, int h, in
  * layer, reorg_layer.c:83), re-expressed for NHWC in and out; reverse!=0 is forward=1 */
 int y2h_reorg(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c,
               int stride, int reverse, y2h_stream s);
+/* [connected] in the reference's accumulation order (connected_layer.c:141-176 / gemm.c:90-106 gemm_nt): input element
+ * k = c*hw + p of batch item b is x[b*x_batch_stride + p*ld + c] (an NHWC producer; hw = 1 for a flat one), weights
+ * w_ref [outputs][hw*c] in the reference layout; BN / bias / activation as for a convolution */
+int y2h_connected_ref(const float *x, long x_batch_stride, int ld, int hw, int c, const float *w_ref, float *y,
+                      int outputs, int batch, int batch_normalize, int activation, const float *mean,
+                      const double *rinv, const float *scale, const float *bias, y2h_stream s);
+/* YOLOv1 head decode (detection_layer.c:222-251): pred = [batch] blocks of pred_stride floats; boxes
+ * [batch][side*side*num][4], probs [batch][side*side*num][classes] */
+int y2h_detection_boxes(const float *pred, long pred_stride, int batch, int side, int num, int classes, int sqrt_flag,
+                        int w, int h, float thresh, int only_objectness, float *boxes, float *probs, y2h_stream s);
 /* residual add (shortcut_layer.c:38-43, blas.c:57-81): out = act(in + add) where the shapes overlap; `add` is
  * w1 x h1 x c1, in/out are w2 x h2 x c2; stride = w1/w2 and sample = w2/w1 (each >= 1) as in shortcut_cpu */
 int y2h_shortcut(const float *in, int ld_in, const float *add, int ld_add, float *out, int ld_out, int batch,

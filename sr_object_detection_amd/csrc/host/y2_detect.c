@@ -78,6 +78,37 @@ void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *b
     y2h_free(d_tmp_map);
 }
 
+/* detection_layer.c:222-251 get_detection_boxes with the reference's host-array signature, decoded on the device.
+ * l.output may be the engine's own output buffer (already in HBM) or a caller-provided tensor (uploaded). */
+void get_detection_boxes(layer l, int w, int h, float thresh, float **probs, box *boxes, int only_objectness)
+{
+    y2_ldev *d = ld_of(&l);
+    y2_engine *e;
+    int total = l.side * l.side * l.n, i;
+    float *d_pred, *d_tmp = NULL, *h_probs;
+    if (l.type != DETECTION || !d || !d->eng || !d->eng->built) { y2_fail("get_detection_boxes: layer is not a prepared detection layer"); return; }
+    if (!l.output) { y2_fail("get_detection_boxes: l.output is NULL"); return; }
+    e = d->eng;
+    if (!e->d_boxes || e->det_total < total) { y2_fail("get_detection_boxes: the detection layer is not the network's output layer"); return; }
+    HIPCALL(y2h_set_device(e->device));
+    if (l.output >= e->h_out && l.output < e->h_out + e->out_floats && (size_t)(l.output - e->h_out) % l.outputs == 0)
+        d_pred = d->d_flat + (l.output - e->h_out);
+    else {
+        HIPCALL(y2h_malloc((void **)&d_tmp, (size_t)l.outputs * sizeof(float)));
+        HIPCALL(y2h_memcpy_h2d(d_tmp, l.output, (size_t)l.outputs * sizeof(float), e->stream));
+        d_pred = d_tmp;
+    }
+    HIPCALL(y2h_detection_boxes(d_pred, (long)l.outputs, 1, l.side, l.n, l.classes, l.sqrt, w, h, thresh, only_objectness,
+                                e->d_boxes, e->d_probs, e->stream));
+    h_probs = malloc((size_t)total * l.classes * sizeof(float));
+    HIPCALL(y2h_memcpy_d2h(boxes, e->d_boxes, (size_t)total * sizeof(box), e->stream));
+    HIPCALL(y2h_memcpy_d2h(h_probs, e->d_probs, (size_t)total * l.classes * sizeof(float), e->stream));
+    HIPCALL(y2h_stream_sync(e->stream));
+    for (i = 0; i < total; ++i) memcpy(probs[i], h_probs + (size_t)i * l.classes, l.classes * sizeof(float));
+    free(h_probs);
+    y2h_free(d_tmp);
+}
+
 /* scratch for the array-in/array-out NMS entry points (not thread-safe, like the reference) */
 static struct { float *d_boxes, *d_probs, *d_probs_in; int *d_counts; size_t boxes_cap, probs_cap, counts_cap; y2h_stream stream; int device; } g_nms = {0, 0, 0, 0, 0, 0, 0, 0, -1};
 
@@ -248,10 +279,14 @@ static int detect_from(network net, float *d_pred, float thresh, float nms, int 
     if (!e || !e->built) { y2_fail("y2_detect_resident: run a forward first"); return -1; }
     l = &net.layers[e->out_layer];
     d = ld_of(l);
-    if (l->type != REGION) { y2_fail("y2_detect_resident: the network does not end in a region layer"); return -1; }
+    if (l->type != REGION && l->type != DETECTION) { y2_fail("y2_detect_resident: the network does not end in a region or detection layer"); return -1; }
     HIPCALL_I(y2h_set_device(e->device));
-    if (!d_pred) d_pred = d->d_region;
+    if (!d_pred) d_pred = l->type == REGION ? d->d_region : d->d_flat;
     memset(&q, 0, sizeof q);
+    if (l->type == DETECTION) {           /* YOLOv1 head: detection_layer.c:222 decode, then the same NMS / compaction */
+        HIPCALL_I(y2h_detection_boxes(d_pred, (long)l->outputs, net.batch, l->side, l->n, l->classes, l->sqrt, img_w, img_h,
+                                      thresh, 0, e->d_boxes, e->d_probs, e->stream));
+    } else {
     q.batch = net.batch; q.w = l->w; q.h = l->h; q.num = l->n; q.classes = l->classes;
     q.img_w = img_w; q.img_h = img_h; q.thresh = thresh; q.classfix = l->classfix;
     q.anchors = d->d_anchors;
@@ -259,6 +294,7 @@ static int detect_from(network net, float *d_pred, float thresh, float nms, int 
     q.tree_order = d->d_tree_order; q.tree_level_off = d->d_tree_loff; q.tree_levels = d->tree_levels;
     q.pred = d_pred; q.boxes = e->d_boxes; q.probs = e->d_probs;
     HIPCALL_I(y2h_region_boxes(&q, e->stream));
+    }
     final_probs = e->d_probs;
     if (nms > 0) {
         HIPCALL_I(y2h_memcpy_d2d(e->d_probs_nms, e->d_probs, (size_t)net.batch * e->det_total * l->classes * sizeof(float), e->stream));

@@ -203,6 +203,26 @@ static void input_view(const network *net, int i, const float **x, int *ldx)
     const y2_engine *e = y2_engine_of(net);
     if (i == 0) { *x = e->d_in_nhwc; *ldx = (e->in_halo == 2) ? 4 : net->c; }
     else { const y2_ldev *p = ld_of(&net->layers[i - 1]); *x = p->out; *ldx = p->out_ld; }
+    /* a [connected] layer is run as a 1x1 convolution over a 1x1 image whose channels are the whole input vector */
+    if (net->layers[i].type == CONNECTED) *ldx = net->layers[i].inputs;
+}
+
+/* the layer whose activations a layer reads, looking through the inference no-ops ([dropout], [cost]) */
+static int producer_of(const network *net, int i)
+{
+    int p = i - 1;
+    while (p > 0 && (net->layers[p].type == DROPOUT || net->layers[p].type == COST)) --p;
+    return p;
+}
+
+/* 1: the layer's activations are a flat [batch][outputs] fp32 vector, not an NHWC image */
+static int is_flat(const network *net, int i)
+{
+    switch (net->layers[i].type) {
+    case REGION: case AVGPOOL: case SOFTMAX: case CONNECTED: case DETECTION: return 1;
+    case DROPOUT: case COST: return i > 0 ? is_flat(net, i - 1) : 0;
+    default: return 0;
+    }
 }
 
 static int upload_small(void **dst, const void *src, size_t bytes, y2h_stream s)
@@ -252,9 +272,21 @@ static int upload_weights(network *net)
         float *wp, *b;
         int K, co, ci, kh, kw, f;
         const int w_half = (i > 0) && ld_of(&net->layers[i - 1])->out_half;   /* half input -> half weights */
-        if (l->type != CONVOLUTIONAL) continue;
+        if (l->type != CONVOLUTIONAL && l->type != CONNECTED) continue;
         K = l->size * l->size * l->c;
         wp = (float *)(host + d->off_w_packed);
+        if (l->type == CONNECTED) {
+            /* [outputs][inputs]: the reference flattens an image producer as [c][y][x], our activations are
+             * [y][x][c], so input k = c*HW + p moves to p*C + c; a flat producer keeps its order */
+            const layer *pl = i > 0 ? &net->layers[producer_of(net, i)] : NULL;
+            const int hw = (pl && !is_flat(net, producer_of(net, i))) ? pl->out_h * pl->out_w : 1;
+            const int C = K / (hw > 0 ? hw : 1);
+            int pix;
+            for (co = 0; co < l->n; ++co)
+                for (ci = 0; ci < C; ++ci)
+                    for (pix = 0; pix < hw; ++pix)
+                        wp[(size_t)co * K + (size_t)pix * C + ci] = l->weights[(size_t)co * K + (size_t)ci * hw + pix];
+        } else
         /* reference layout [n][c][kh][kw] (im2col.c:24-27) -> kernel layout [n][kh][kw][c] */
         for (co = 0; co < l->n; ++co)
             for (ci = 0; ci < l->c; ++ci)
@@ -384,7 +416,8 @@ int y2_engine_build(network *net)
                 if (pd && pd->out_half) { y2_fail("fp16 mode: layer %d (%s) needs an fp32 producer (a convolutional or avgpool layer)", i, get_layer_string(l->type)); return -1; }
                 break;
             case COST: d->out_half = pd ? pd->out_half : 0; break;
-            case SHORTCUT: y2_fail("fp16 mode: [shortcut] (layer %d) has no half-precision kernel", i); return -1;
+            case SHORTCUT: case CONNECTED: case DETECTION: case DROPOUT:
+                y2_fail("fp16 mode: layer %d (%s) has no half-precision kernel", i, get_layer_string(l->type)); return -1;
             default: break;
             }
         }
@@ -448,6 +481,27 @@ int y2_engine_build(network *net)
             d->out = d->d_flat; d->out_ld = l->outputs;
             d->kernel = l->type == AVGPOOL ? "avgpool" : "softmax_rows";
             break;
+        case CONNECTED: case DETECTION: {
+            /* YOLOv1 family: flat fp32 vectors.  The producer of a dense layer must be contiguous (an image
+             * producer is read as [y][x][c] with re-ordered weights, see upload_weights) */
+            const int pi = producer_of(net, i);
+            const y2_ldev *pd = i > 0 ? ld_of(&net->layers[pi]) : NULL;
+            if (i == 0) { y2_fail("layer %d (%s) cannot be the first layer", i, get_layer_string(l->type)); return -1; }
+            if (!is_flat(net, pi) && (pd->out_ld != net->layers[pi].out_c || pd->fused_pool)) {
+                y2_fail("layer %d (%s): its input (layer %d) is not stored contiguously", i, get_layer_string(l->type), pi);
+                return -1;
+            }
+            if (l->type == DETECTION && !is_flat(net, pi)) { y2_fail("detection layer %d must follow a flat layer ([connected])", i); return -1; }
+            HIPCALL(y2h_malloc((void **)&d->d_flat, (size_t)l->batch * l->outputs * sizeof(float)));
+            d->out = d->d_flat; d->out_ld = l->outputs;
+            d->kernel = l->type == DETECTION ? (l->softmax ? "detection(copy+softmax)" : "detection(copy)") : "connected";
+        } break;
+        case DROPOUT: {
+            y2_ldev *sd = i > 0 ? ld_of(&net->layers[i - 1]) : NULL;
+            if (!sd) { y2_fail("dropout layer %d has no input layer", i); return -1; }
+            d->alias_of = i - 1;
+            d->out = sd->out; d->out_ld = sd->out_ld; d->kernel = "none (inference)";
+        } break;
         default:
             y2_fail("layer %d: type %d has no device implementation", i, (int)l->type);
             return -1;
@@ -490,8 +544,8 @@ int y2_engine_build(network *net)
         if (!e->h_out) { y2_fail("out of host memory for the network output"); return -1; }
         if (!e->h_out_pinned && y2h_host_register(e->h_out, e->h_out_cap * sizeof(float)) == 0) e->h_out_pinned = 1;
         HIPCALL(y2h_malloc((void **)&e->d_out_nchw, e->out_floats * sizeof(float)));
-        if (ol->type == REGION) {
-            e->det_total = ol->w * ol->h * ol->n;
+        if (ol->type == REGION || ol->type == DETECTION) {
+            e->det_total = ol->w * ol->h * ol->n;         /* a [detection] layer has w = h = side */
             e->det_classes = ol->classes;
             e->det_batch = net->batch;
             e->det_cap = e->det_total;
@@ -560,7 +614,7 @@ int y2_engine_build(network *net)
         const float *x; int ldx;
         size_t wbytes;
         int w_half;
-        if (l->type != CONVOLUTIONAL) continue;
+        if (l->type != CONVOLUTIONAL && l->type != CONNECTED) continue;
         if (l->activation != LINEAR && l->activation != LEAKY && l->activation != LOGISTIC && l->activation != RELU) {
             y2_fail("layer %d: activation %d is not implemented on the device", i, (int)l->activation);
             return -1;
@@ -595,6 +649,7 @@ int y2_engine_build(network *net)
             d->off_rinv = off; off = align_up(off + l->n * sizeof(double), 64);
         }
         d->kernel = y2h_conv_variant(&c, e->strict);
+        if (l->type == CONNECTED && !d->uses_mfma) d->kernel = "connected_ref";
         if (d->fused_pool) { snprintf(d->kname, sizeof d->kname, "%s+maxpool2", d->kernel); d->kernel = d->kname; }
     }
     {   /* split-K scratch: the largest request of any conv layer */
@@ -603,7 +658,7 @@ int y2_engine_build(network *net)
             y2h_conv c;
             const float *x; int ldx;
             size_t b;
-            if (net->layers[i].type != CONVOLUTIONAL || e->strict) continue;
+            if ((net->layers[i].type != CONVOLUTIONAL && net->layers[i].type != CONNECTED) || e->strict) continue;
             input_view(net, i, &x, &ldx);
             conv_desc(net, i, &c, x, ldx);
             c.w_packed = (const float *)(uintptr_t)256;
@@ -731,6 +786,32 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
             if (l->softmax_tree) { y2_fail("softmax layer with tree= is not implemented on the device"); return -1; }
             HIPCALL(y2h_softmax_rows(x, d->d_flat, (long)l->batch * l->groups, l->inputs / l->groups, l->temperature, e->stream));
         } break;
+        case CONNECTED: {
+            /* connected_layer.c:141-176.  Fast path: a 1x1 convolution over a 1x1 image on the matrix cores (weights
+             * re-ordered for an NHWC producer at upload); otherwise, and in strict mode, the reference-order kernel */
+            y2h_conv c;
+            conv_desc(net, i, &c, x, ldx);
+            if (d->uses_mfma && !e->strict) HIPCALL(y2h_conv_forward(&c, 0, e->stream));
+            else {
+                const int pi = producer_of(net, i);
+                const layer *pl = &net->layers[pi];
+                const int flat = is_flat(net, pi);
+                const int hw = flat ? 1 : pl->out_h * pl->out_w, cc = l->inputs / hw;
+                HIPCALL(y2h_connected_ref(x, (long)l->inputs, flat ? cc : ld_of(pl)->out_ld, hw, cc, c.w_ref, d->d_flat, l->outputs,
+                                          l->batch, l->batch_normalize, c.activation, c.mean, c.rinv, c.scale, c.bias, e->stream));
+            }
+        } break;
+        case DROPOUT:
+            break;                    /* dropout_layer.c:34: nothing happens at inference; the output is the input */
+        case DETECTION: {
+            /* detection_layer.c:49-66 at inference: copy, then a softmax over every cell's class scores */
+            int b;
+            HIPCALL(y2h_memcpy_d2d(d->d_flat, x, (size_t)l->batch * l->outputs * sizeof(float), e->stream));
+            if (l->softmax)
+                for (b = 0; b < l->batch; ++b)
+                    HIPCALL(y2h_softmax_rows(d->d_flat + (size_t)b * l->outputs, d->d_flat + (size_t)b * l->outputs,
+                                             (long)l->side * l->side, l->classes, 1.f, e->stream));
+        } break;
         case SHORTCUT: {
             const y2_ldev *fd = ld_of(&net->layers[l->index]);
             int act = l->activation == LEAKY ? Y2H_ACT_LEAKY : l->activation == LOGISTIC ? Y2H_ACT_LOGISTIC :
@@ -758,7 +839,7 @@ int y2_engine_fetch_output(network *net)
     layer *l = &net->layers[e->out_layer];
     y2_ldev *d = ld_of(l);
     const float *src;
-    if (l->type == REGION || l->type == AVGPOOL || l->type == SOFTMAX) src = d->out;
+    if (is_flat(net, e->out_layer)) src = d->out;
     else {
         if (d->out_half)
             HIPCALL(y2h_nhwc_f16_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
@@ -887,7 +968,7 @@ int y2_pull_layer_output(network net, int i, float *dst)
         return -1;
     }
     HIPCALL(y2h_set_device(e->device));
-    if (l->type == REGION || l->type == AVGPOOL || l->type == SOFTMAX || (l->type == COST && (l->out_h == 0 || l->out_w == 0))) {
+    if (is_flat(&net, i)) {
         HIPCALL(y2h_memcpy_d2h(dst, d->out, n * sizeof(float), e->stream));
         HIPCALL(y2h_stream_sync(e->stream));
         return 0;
@@ -1035,6 +1116,9 @@ char *get_layer_string(LAYER_TYPE a)         /* network.c:73-130 */
     case SOFTMAX: return "softmax";
     case COST: return "cost";
     case SHORTCUT: return "shortcut";
+    case CONNECTED: return "connected";
+    case DROPOUT: return "dropout";
+    case DETECTION: return "detection";
     default: return "none";
     }
 }

@@ -778,3 +778,50 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }
+
+// ---------------------------------------------------------------------------
+// [connected] in the reference's own accumulation order (connected_layer.c:141-176: gemm(0,1,..) = gemm_nt,
+// gemm.c:90-106: sum over k ascending of separately rounded products, then C += sum), for the strict mode and for
+// shapes the matrix-core kernel does not take.  The input vector of the reference is the producer's output flattened
+// as [c][y][x]; here the producer's activations are NHWC, so element k = c*HW + p is read at pixel p, channel c.
+// Epilogue = the convolution's (normalize / scale / bias / activation on a 1x1 "image").
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void connected_ref_kernel(const float *__restrict__ x, long x_batch_stride, int ld, int HW, int C,
+                                                            const float *__restrict__ w, float *__restrict__ y, int outputs,
+                                                            int batch, ConvK a)
+{
+    const long total = (long)batch * outputs;
+    const int K = HW * C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int o = (int)(idx % outputs);
+        const long b = idx / outputs;
+        const float *xb = x + b * x_batch_stride;
+        const float *wr = w + (size_t)o * K;
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c)
+            for (int p = 0; p < HW; ++p) {
+                const float prod = xb[(size_t)p * ld + c] * wr[(size_t)c * HW + p];
+                sum = sum + prod;
+            }
+        sum = 0.f + sum;
+        float mean = 0.f, scale = 1.f;
+        double rinv = 1.0;
+        if (a.bn) { mean = a.mean[o]; rinv = a.rinv[o]; scale = a.scale[o]; }
+        y[idx] = epilogue(sum, a.bn, mean, rinv, scale, a.bias[o], a.act);
+    }
+}
+
+extern "C" int y2h_connected_ref(const float *x, long x_batch_stride, int ld, int hw, int c, const float *w_ref, float *y,
+                                 int outputs, int batch, int batch_normalize, int activation, const float *mean,
+                                 const double *rinv, const float *scale, const float *bias, y2h_stream s)
+{
+    if (!x || !w_ref || !y || !bias || hw <= 0 || c <= 0 || outputs <= 0 || batch <= 0 || ld < c) return Y2H_EINVAL;
+    if (batch_normalize && (!mean || !rinv || !scale)) return Y2H_EINVAL;
+    ConvK a;
+    memset(&a, 0, sizeof a);
+    a.mean = mean; a.rinv = rinv; a.scale = scale; a.bias = bias; a.bn = batch_normalize; a.act = activation;
+    hipLaunchKernelGGL(connected_ref_kernel, dim3(y2h_grid((long)batch * outputs, 256)), dim3(256), 0, S(s), x, x_batch_stride,
+                       ld, hw, c, w_ref, y, outputs, batch, a);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

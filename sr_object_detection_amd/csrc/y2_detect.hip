@@ -566,3 +566,53 @@ extern "C" int y2h_resize_chw(const float *src, int c, int ih, int iw, float *tm
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }
+
+// ---------------------------------------------------------------------------
+// YOLOv1 head decode: detection_layer.c:222-251 get_detection_boxes.  pred = one [detection] output per batch
+// item: side*side*classes class scores, side*side*num box confidences, side*side*num*4 box terms.
+// One thread per (image, cell, box); the C expressions are mirrored operand for operand: (p + col) / side * w in
+// fp32 with the int operands converted, pow(p, sqrt ? 2 : 1) * w in double (p*p is exact in double, which is what
+// glibc's pow returns for the exponent 2), prob = scale * class score, kept when > thresh.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void detection_boxes_kernel(const float *__restrict__ pred, long pred_stride, int batch, int side,
+                                                              int num, int classes, int sq, int w, int h, float thresh,
+                                                              int only_objectness, float *__restrict__ boxes,
+                                                              float *__restrict__ probs)
+{
+    const long per = (long)side * side * num;
+    const long total = per * batch;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long b = idx / per;
+        const int index = (int)(idx - b * per);          // i*num + n
+        const int i = index / num;
+        const int row = i / side, col = i % side;
+        const float *p = pred + b * pred_stride;
+        const float scale = p[(long)side * side * classes + index];
+        const float *bx = p + (long)side * side * (classes + num) + (long)index * 4;
+        float *ob = boxes + idx * 4;
+        ob[0] = (bx[0] + col) / side * w;
+        ob[1] = (bx[1] + row) / side * h;
+        const double pw = sq ? (double)bx[2] * (double)bx[2] : (double)bx[2];
+        const double ph = sq ? (double)bx[3] * (double)bx[3] : (double)bx[3];
+        ob[2] = (float)(pw * w);
+        ob[3] = (float)(ph * h);
+        float *op = probs + idx * classes;
+        const float *cls = p + (long)i * classes;
+        for (int j = 0; j < classes; ++j) {
+            const float prob = scale * cls[j];
+            op[j] = (prob > thresh) ? prob : 0.f;
+        }
+        if (only_objectness) op[0] = scale;
+    }
+}
+
+extern "C" int y2h_detection_boxes(const float *pred, long pred_stride, int batch, int side, int num, int classes, int sqrt_flag,
+                                   int w, int h, float thresh, int only_objectness, float *boxes, float *probs, y2h_stream s)
+{
+    if (!pred || !boxes || !probs || batch <= 0 || side <= 0 || num <= 0 || classes <= 0) return Y2H_EINVAL;
+    const long total = (long)batch * side * side * num;
+    hipLaunchKernelGGL(detection_boxes_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), pred, pred_stride, batch, side, num,
+                       classes, sqrt_flag, w, h, thresh, only_objectness, boxes, probs);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

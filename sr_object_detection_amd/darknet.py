@@ -321,9 +321,23 @@ class Network:
         rows = _rows(probs)
         mp = l.map if (use_map and l.map) else None
         L.get_region_boxes(l, w, h, thresh, rows, _ptr(boxes), only_objectness, mp)
-        err = _check()
         if L.y2_failed_and_clear():
-            raise Y2Error("get_region_boxes: " + err)
+            raise Y2Error("get_region_boxes: " + _check())
+        return boxes, probs
+
+    def get_detection_boxes(self, w: int, h: int, thresh: float, only_objectness: int = 0, batch_item: int = 0):
+        """YOLOv1 head: detection_layer.c:222 -> (boxes[side*side*num,4], probs[side*side*num,classes])"""
+        L = lib()
+        L.get_detection_boxes.argtypes = [Layer, C.c_int, C.c_int, C.c_float, C.POINTER(C.POINTER(C.c_float)), C.c_void_p, C.c_int]
+        l = Layer.from_buffer_copy(self.last)
+        total = l.side * l.side * l.n
+        if batch_item:
+            l.output = C.cast(C.addressof(l.output.contents) + batch_item * l.outputs * 4, C.POINTER(C.c_float))
+        boxes = np.zeros((total, 4), dtype=np.float32)
+        probs = np.zeros((total, l.classes), dtype=np.float32)
+        L.get_detection_boxes(l, w, h, thresh, _rows(probs), _ptr(boxes), only_objectness)
+        if L.y2_failed_and_clear():
+            raise Y2Error("get_detection_boxes: " + _check())
         return boxes, probs
 
     def test_detector_img(self, im: np.ndarray, thresh: float, names=None):

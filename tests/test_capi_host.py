@@ -60,7 +60,7 @@ def table_of(net):
     return rows
 
 
-@pytest.mark.parametrize("name,size,batch", [("mini", 32, 2), ("mini-mfma", 64, 2), ("mini-res", 32, 2), ("tiny-yolo-voc", 416, 1),
+@pytest.mark.parametrize("name,size,batch", [("mini", 32, 2), ("mini-mfma", 64, 2), ("mini-res", 32, 2), ("mini-v1", 32, 2), ("tiny-yolo-v1", 448, 1), ("tiny-yolo-voc", 416, 1),
                                              ("yolo", 608, 4), ("darknet19", 448, 2), ("yolo9000", 544, 1)])
 def test_cfg_parse_matches_oracle_and_zoo(oracle, workdir, name, size, batch):
     cfg, _, _ = materialize(workdir, name, size, batch, 1) if name in ("mini", "mini-mfma") else (None, None, None)
@@ -159,7 +159,7 @@ def test_errors_are_loud(workdir):
     with pytest.raises(darknet.Y2Error):
         darknet.Network.parse_network_cfg(os.path.join(workdir, "does_not_exist.cfg"))
     bad = os.path.join(workdir, "bad.cfg")
-    open(bad, "w").write("[net]\nbatch=1\nwidth=32\nheight=32\nchannels=3\n\n[connected]\noutput=10\n")
+    open(bad, "w").write("[net]\nbatch=1\nwidth=32\nheight=32\nchannels=3\n\n[local]\nfilters=10\n")
     with pytest.raises(darknet.Y2Error, match="outside"):
         darknet.Network.parse_network_cfg(bad)
     cfg, wts, x = materialize(workdir, "mini", 32, 1, 5)
