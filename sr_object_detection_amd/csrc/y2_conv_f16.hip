@@ -27,7 +27,7 @@
 #define ABL(bit) false
 #endif
 
-template <int BM, int BN, int BK, int KS, int WM, int WN, int MINB, bool DB>
+template <int BM, int BN, int BK, int KS, int WM, int WN, int MINB, bool DB, bool M16>
 __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK a)
 {
     constexpr int NT = WM * WN * 64;
@@ -37,6 +37,10 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
     constexpr int PA = (BM + RP - 1) / RP, PB = (BN + RP - 1) / RP;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NG = BK / 16;           // MFMA k-steps per staged slice
+    // M16: the contraction runs on v_mfma_f32_16x16x32_f16 (same FLOP per cycle; under a dense matrix load the chip
+    // holds a higher clock with this shape than with 32x32x16 -- MI355X_MICROARCH.md clock notes); the wave tile is
+    // then 2*TM x 2*TN tiles of 16x16 and a lane's four accumulator registers are four consecutive GEMM rows
+    constexpr int TM6 = 2 * TM, TN6 = 2 * TN, HM = TM;      // HM = 16-row tiles per half sub-group
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
     static_assert(NG >= 2, "the pipelined K-step needs at least two k-groups per slice");
 
@@ -96,7 +100,8 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+    f32x4 acc6[M16 ? TM6 : 1][M16 ? TN6 : 1];
     f32x4 ra[PA], rb[PB];
 
     auto tile_at = [&](int i) -> int {
@@ -153,16 +158,54 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
         const int ct = tile_at(cti);
         if (ct >= a.ntiles) break;
         const int p0 = (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < TM6; ++i)
+#pragma unroll
+                for (int j = 0; j < TN6; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc6[i][j][r] = 0.f;
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
         for (int kt = 0; kt < nk; ++kt) {
             // hop of the staging cursor to the workgroup's next tile: here, outside the K-step body, so that
             // the body stays one scheduling region
             if (stage_k == nk) { setup_tile(tile_at(++lti)); stage_k = 0; }
+            if constexpr (M16) {
+                // lane (row l16, quarter lq) of a 16x16x32 operand holds k = 8*lq .. 8*lq+7 of its row.  A K-step is
+                // 2*(BK/32) sub-groups: the B fragments of a 32-deep group are read once, the A row-tiles in two halves
+                const int l16 = lane & 15, lq = lane >> 4;
+                const _Float16 *As6 = smem_h + cur * BUF + (wm * (BM / WM) + l16) * LS + lq * 8;
+                const _Float16 *Bs6 = smem_h + cur * BUF + BM * LS + (wn * (BN / WN) + l16) * LS + lq * 8;
+                f16x8 af6[HM], bf6[TN6];
+#pragma unroll
+                for (int kg = 0; kg < BK / 32; ++kg)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        if (hf == 0) {
+#pragma unroll
+                            for (int j = 0; j < TN6; ++j) bf6[j] = *(const f16x8 *)&Bs6[j * 16 * LS + kg * 32];
+                        }
+#pragma unroll
+                        for (int i = 0; i < HM; ++i) af6[i] = *(const f16x8 *)&As6[(hf * HM + i) * 16 * LS + kg * 32];
+                        if (kg == 0 && hf == 0) store_slice(cur ^ 1);     // the slice loaded one step ago
+                        if (kg == 0 && hf == 1) load_slice();             // two slices ahead
+                        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                        for (int i = 0; i < HM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN6; ++j)
+                                acc6[hf * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af6[i], bf6[j], acc6[hf * HM + i][j], 0, 0, 0);
+                        __builtin_amdgcn_s_setprio(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            } else {
             // lane (row li, half lh) of a 32x32x16 operand holds k = 8*lh .. 8*lh+7 of its row
             const _Float16 *As = smem_h + cur * BUF + (wm * (BM / WM) + li) * LS + lh * 8;
             const _Float16 *Bs = smem_h + cur * BUF + BM * LS + (wn * (BN / WN) + li) * LS + lh * 8;
@@ -224,6 +267,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }   // !M16
             // Raw barrier: wait for this wave's LDS traffic only.  __syncthreads() would also drain vmcnt(0), i.e.
             // wait at every K-step for the global loads of the slice two steps ahead that were just issued --
             // the latency the two-slice distance exists to hide.
@@ -240,8 +284,69 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
             cur ^= 1;
         }
 
-        // epilogue: lane holds filter li of each 32x32 tile and 16 pixels
         _Float16 *yh = (_Float16 *)a.y;
+        if constexpr (M16) {
+            // 16x16 tiles: lane (l16, lq) holds filter l16 and GEMM rows 4*lq .. 4*lq+3 -- with the fused pool exactly
+            // one pooling window.  Two filter tiles (32 filters = 64 bytes per pixel) go through the LDS scratch
+            // together and leave as 16-byte stores (the host selects this variant only when that is possible).
+            constexpr int ES = 40;
+            static_assert(BUF >= WM * WN * 32 * ES, "epilogue scratch must fit in one staging buffer");
+            _Float16 *es = smem_h + (cur ^ 1) * BUF + wv * 32 * ES;
+            const int l16 = lane & 15, lq = lane >> 4;
+            const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
+            if (a.pool) {
+#pragma unroll
+                for (int jp = 0; jp < TN; ++jp) {
+                    const int cb = n0 + wn * (BN / WN) + jp * 32;
+                    const int c0f = cb + l16, c1f = cb + 16 + l16;
+                    const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
+                    const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
+#pragma unroll
+                    for (int ip = 0; ip < TM; ++ip) {                 // two 16-row tiles = 8 pooled rows
+                        const int pb = p0 + wm * (BM / WM) + ip * 32;
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti) {
+                            const f32x4 q0 = acc6[2 * ip + ti][2 * jp], q1 = acc6[2 * ip + ti][2 * jp + 1];
+                            float m0 = epilogue_fast(q0[0], al0, be0, a.act), m1 = epilogue_fast(q1[0], al1, be1, a.act);
+#pragma unroll
+                            for (int u = 1; u < 4; ++u) {
+                                m0 = __builtin_fmaxf(m0, epilogue_fast(q0[u], al0, be0, a.act));
+                                m1 = __builtin_fmaxf(m1, epilogue_fast(q1[u], al1, be1, a.act));
+                            }
+                            es[(ti * 4 + lq) * ES + l16] = (_Float16)m0;
+                            es[(ti * 4 + lq) * ES + 16 + l16] = (_Float16)m1;
+                        }
+                        const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+                        const int prow = (pb >> 2) + rrow;
+                        if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int jp = 0; jp < TN; ++jp) {
+                    const int cb = n0 + wn * (BN / WN) + jp * 32;
+                    const int c0f = cb + l16, c1f = cb + 16 + l16;
+                    const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
+                    const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
+#pragma unroll
+                    for (int i6 = 0; i6 < TM6; ++i6) {
+                        const int pb = p0 + wm * (BM / WM) + i6 * 16;
+                        const f32x4 q0 = acc6[i6][2 * jp], q1 = acc6[i6][2 * jp + 1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            es[(lq * 4 + r) * ES + l16] = (_Float16)epilogue_fast(q0[r], al0, be0, a.act);
+                            es[(lq * 4 + r) * ES + 16 + l16] = (_Float16)epilogue_fast(q1[r], al1, be1, a.act);
+                        }
+                        const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+                        const int p = pb + rrow;
+                        if (p < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+        // epilogue: lane holds filter li of each 32x32 tile and 16 pixels
         if (a.vec_store) {
             // Half outputs go out as 16-byte stores: a lane of the accumulator layout owns ONE filter of 16
             // pixels, which would be sixteen 2-byte stores per 32x32 tile (measured: 38 % of the kernel).  Each
@@ -342,29 +447,32 @@ struct VariantH {
     size_t lds;
     int threads;
     int minb;
+    bool m16;          // 16x16x32 MFMA variant: needs the 16-byte output stores (vec_store)
     bool attr_set[16];
 };
 
 // MINB = workgroups per CU the register budget is sized for: 4-wave kernels with MINB 1 get the whole
 // 512-entry register file of their SIMD (one wave per SIMD), everything else 256 registers per lane
-#define VARH(BM, BN, BK, KS, WM, WN, MINB, DB)                                                    \
-    { "conv_mfma_f16_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_f16_kernel<BM, BN, BK, KS, WM, WN, MINB, DB>, \
-      (size_t)2 * (BM + BN) * (BK + 8) * sizeof(_Float16), WM * WN * 64, MINB, {false} }
+#define VARH(BM, BN, BK, KS, WM, WN, MINB, DB, M16)                                                  \
+    { "conv_mfma_f16_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_f16_kernel<BM, BN, BK, KS, WM, WN, MINB, DB, M16>, \
+      (size_t)2 * (BM + BN) * (BK + 8) * sizeof(_Float16), WM * WN * 64, MINB, M16, {false} }
 
 static VariantH g_variants_h[] = {
     // 256x256: eight waves of 128x64 (eight accumulator tiles each), two waves per SIMD, ONE workgroup per CU
-    VARH(256, 256, 64, 3, 2, 4, 1, false), VARH(256, 256, 64, 1, 2, 4, 1, false),
-    VARH(256, 256, 32, 3, 2, 4, 1, false), VARH(256, 256, 32, 1, 2, 4, 1, false),
-    VARH(256, 128, 64, 3, 4, 2, 1, true), VARH(256, 128, 64, 1, 4, 2, 1, true),
-    VARH(256, 128, 32, 3, 4, 2, 1, true), VARH(256, 128, 32, 1, 4, 2, 1, true),
-    VARH(256, 64, 64, 3, 4, 2, 1, true),  VARH(256, 64, 64, 1, 4, 2, 1, true),
-    VARH(256, 64, 32, 3, 4, 2, 1, true),  VARH(256, 64, 32, 1, 4, 2, 1, true),
-    VARH(128, 128, 64, 3, 2, 2, 2, true), VARH(128, 128, 64, 1, 2, 2, 2, true),
-    VARH(128, 128, 32, 3, 2, 2, 2, true), VARH(128, 128, 32, 1, 2, 2, 2, true),
-    VARH(128, 64, 64, 3, 2, 2, 2, true),  VARH(128, 64, 64, 1, 2, 2, 2, true),
-    VARH(128, 64, 32, 3, 2, 2, 2, true),  VARH(128, 64, 32, 1, 2, 2, 2, true),
-    VARH(64, 64, 64, 3, 2, 2, 2, true),   VARH(64, 64, 64, 1, 2, 2, 2, true),
-    VARH(64, 64, 32, 3, 2, 2, 2, true),   VARH(64, 64, 32, 1, 2, 2, 2, true),
+    VARH(256, 256, 64, 3, 2, 4, 1, false, true), VARH(256, 256, 64, 1, 2, 4, 1, false, true),
+    VARH(256, 256, 32, 3, 2, 4, 1, false, true), VARH(256, 256, 32, 1, 2, 4, 1, false, true),
+    VARH(256, 256, 64, 3, 2, 4, 1, false, false), VARH(256, 256, 64, 1, 2, 4, 1, false, false),
+    VARH(256, 256, 32, 3, 2, 4, 1, false, false), VARH(256, 256, 32, 1, 2, 4, 1, false, false),
+    VARH(256, 128, 64, 3, 4, 2, 1, true, false), VARH(256, 128, 64, 1, 4, 2, 1, true, false),
+    VARH(256, 128, 32, 3, 4, 2, 1, true, false), VARH(256, 128, 32, 1, 4, 2, 1, true, false),
+    VARH(256, 64, 64, 3, 4, 2, 1, true, false),  VARH(256, 64, 64, 1, 4, 2, 1, true, false),
+    VARH(256, 64, 32, 3, 4, 2, 1, true, false),  VARH(256, 64, 32, 1, 4, 2, 1, true, false),
+    VARH(128, 128, 64, 3, 2, 2, 2, true, false), VARH(128, 128, 64, 1, 2, 2, 2, true, false),
+    VARH(128, 128, 32, 3, 2, 2, 2, true, false), VARH(128, 128, 32, 1, 2, 2, 2, true, false),
+    VARH(128, 64, 64, 3, 2, 2, 2, true, false),  VARH(128, 64, 64, 1, 2, 2, 2, true, false),
+    VARH(128, 64, 32, 3, 2, 2, 2, true, false),  VARH(128, 64, 32, 1, 2, 2, 2, true, false),
+    VARH(64, 64, 64, 3, 2, 2, 2, true, false),   VARH(64, 64, 64, 1, 2, 2, 2, true, false),
+    VARH(64, 64, 32, 3, 2, 2, 2, true, false),   VARH(64, 64, 32, 1, 2, 2, 2, true, false),
 };
 
 bool y2_f16_conv_ok(const y2h_conv *d)
@@ -399,11 +507,14 @@ static VariantH *pick_h(const y2h_conv *d)
     const long npix = (long)d->batch * d->h * d->w;
     int force_bm = 0, force_bn = 0;
     if (const char *f = getenv("Y2_CONV_TILE")) sscanf(f, "%dx%d", &force_bm, &force_bn);
+    const bool vec_ok = d->y_f16 && d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0;
+    const bool no_m16 = getenv("Y2_NO_M16") != nullptr;      // A/B switch: keep to the 32x32x16 variants
     VariantH *best = nullptr;
     double best_cost = 0;
     for (VariantH &v : g_variants_h) {
         if (v.bk != bk || v.ks != d->size) continue;
         if (force_bm && (v.bm != force_bm || v.bn != force_bn)) continue;
+        if (v.m16 && (!vec_ok || no_m16)) continue;
         const long tiles = ((npix + v.bm - 1) / v.bm) * ((d->n + v.bn - 1) / v.bn);
         const int bpc = bpc_h(v);
         long per_cu;
