@@ -262,6 +262,33 @@ __global__ __launch_bounds__(256) void region_tree_kernel(const float *__restric
     }
 }
 
+// region_kernel with coalesced memory traffic: one thread per box still does the arithmetic (sequential, as the
+// reference), but the rows of the 64 boxes of a workgroup travel through LDS (a box is `size` consecutive floats;
+// thread-strided access to them cost 93 us per 32 frames of yolo.cfg 608).  size is odd for the cfgs of the family
+// (85, 25, 30), so the per-thread LDS rows do not collide on banks.
+__global__ __launch_bounds__(64) void region_lds_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
+                                                        long boxes, int num, int classes, int coords, int softmax)
+{
+    extern __shared__ float rows[];                        // [64][size]
+    const int size = coords + 1 + classes;
+    const long b0 = (long)blockIdx.x * 64;
+    const int nb = (boxes - b0 < 64) ? (int)(boxes - b0) : 64;
+    for (int idx = threadIdx.x; idx < nb * size; idx += 64) {
+        const int bx = idx / size, k = idx - bx * size;
+        const long i = b0 + bx;
+        rows[idx] = x[(i / num) * ldx + (long)(i % num) * size + k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+        float *r = rows + (size_t)threadIdx.x * size;
+        r[coords] = (float)(1. / (1. + exp(-(double)r[coords])));
+        if (softmax == 1) softmax_seq(r + coords + 1, classes, 1.f, r + coords + 1);
+    }
+    __syncthreads();
+    float *dst = y + b0 * size;
+    for (int idx = threadIdx.x; idx < nb * size; idx += 64) dst[idx] = rows[idx];
+}
+
 // Same arithmetic, one workgroup per box: the class scores of the box are staged through LDS with coalesced
 // loads, every thread then walks whole groups sequentially (the reference's order inside a group, softmax_seq),
 // and the result leaves coalesced.  The thread-per-(box,group) kernel above reads and writes 4-byte pieces
@@ -291,8 +318,13 @@ extern "C" int y2h_region_forward(const float *x, int ldx, float *y, int batch, 
     if (ldx < num * (coords + 1 + classes)) return Y2H_EINVAL;
     const long boxes = (long)batch * hw * num;
     const int mode = groups > 0 ? 2 : (softmax ? 1 : 0);
-    hipLaunchKernelGGL(region_kernel, dim3((unsigned)((boxes + 63) / 64)), dim3(64), 0, S(s),
-                       x, ldx, y, boxes, hw, num, classes, coords, mode);
+    const size_t row_bytes = (size_t)64 * (coords + 1 + classes) * sizeof(float);
+    if (mode != 2 && row_bytes <= 64 * 1024)
+        hipLaunchKernelGGL(region_lds_kernel, dim3((unsigned)((boxes + 63) / 64)), dim3(64), row_bytes, S(s),
+                           x, ldx, y, boxes, num, classes, coords, mode);
+    else    // tree heads (their class scores are rewritten by the tree kernel below) and very wide rows
+        hipLaunchKernelGGL(region_kernel, dim3((unsigned)((boxes + 63) / 64)), dim3(64), 0, S(s),
+                           x, ldx, y, boxes, hw, num, classes, coords, mode);
     Y2H_LAUNCH_CHECK();
     if (groups > 0) {
         if (!group_size || !group_offset) return Y2H_EINVAL;
