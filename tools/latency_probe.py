@@ -39,7 +39,7 @@ def main():
     net.load_weights(wts)
     x = synth.image_batch(1, 3, size, size)
     cam = synth.image_batch(1, 4, 480, 640, seed=3)[0]
-    cam_u8 = (cam.transpose(1, 2, 0) * 255).astype(np.uint8)[None]
+    cam_u8 = np.ascontiguousarray((cam.transpose(1, 2, 0) * 255).astype(np.uint8))[None]   # C-contiguous, like a capture buffer
     import torch
     d_x = torch.from_numpy(x).cuda()
     res = {
