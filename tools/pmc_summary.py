@@ -26,7 +26,11 @@ def load(d, tag):
         if k in rows:
             rows[k]["us"] = (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3
     ids = [k for k in rows if rows[k]["name"].startswith("nchw_to_nhwc")]
-    return [rows[k] for k in rows if k >= ids[-1] and "conv" in rows[k]["name"]]
+    want_conv = not OTHER
+    return [rows[k] for k in rows if k >= ids[-1] and (("conv" in rows[k]["name"]) == want_conv)]
+
+
+OTHER = "--other" in sys.argv      # --other: the step's non-convolution kernels (layout, pools, region head, decode, NMS)
 
 
 def main():
