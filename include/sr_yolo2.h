@@ -129,6 +129,9 @@ struct layer {
     /* YOLOv1 family: [detection] grid side and `forced`, [dropout] probability */
     int side, forced;
     float probability;
+    /* [crop] (crop_layer.c:16-46; `scale` above holds crop_height / h for resize_crop_layer) */
+    int flip, noadjust;
+    float angle, saturation, exposure, shift;
 };
 
 /* network.h:19-67, forward-path subset */

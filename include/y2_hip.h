@@ -157,6 +157,19 @@ int y2h_detection_boxes(const float *pred, long pred_stride, int batch, int side
  * w1 x h1 x c1, in/out are w2 x h2 x c2; stride = w1/w2 and sample = w2/w1 (each >= 1) as in shortcut_cpu */
 int y2h_shortcut(const float *in, int ld_in, const float *add, int ld_add, float *out, int ld_out, int batch,
                  int w1, int h1, int c1, int w2, int h2, int c2, int activation, y2h_stream s);
+/* [crop] at inference (crop_layer.c:69-105, !state.train): centred out_h x out_w window, x*2-1 unless noadjust */
+int y2h_crop(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c, int out_h, int out_w,
+             int noadjust, y2h_stream s);
+/* standalone [batchnorm] at inference (batchnorm_layer.c:122-146): ((x - mean) * rinv) * scale per channel, rinv =
+ * 1 / (sqrt(var) + 1e-6f) prepared in double (blas.c:122) */
+int y2h_batchnorm(const float *x, int ldx, float *y, int ldy, long pixels, int c, const float *mean, const double *rinv,
+                  const float *scale, y2h_stream s);
+/* [local] (local_layer.c:95-126): per-location filter banks.  w_packed [location][filter][kh][kw][c], bias_packed
+ * [location][filter] (the engine re-orders the reference's [location][filter][c][kh][kw] / [filter][location]);
+ * strict = 1 runs the reference's summation order (bias first, taps in c,kh,kw order, one rounding per step) */
+int y2h_local(const float *x, int ldx, const float *w_packed, const float *bias_packed, float *y, int ldy, int batch,
+              int h, int w, int c, int n, int size, int stride, int pad, int out_h, int out_w, int activation,
+              int strict, y2h_stream s);
 /* global average pool: [batch][h*w][ld] -> [batch][c] (sequential fp32 sum, avgpool_layer.c:40) */
 int y2h_avgpool(const float *x, int ldx, float *y, int batch, int h, int w, int c, y2h_stream s);
 /* rows of `n` floats: softmax with temperature (blas.c:205); in/out may alias */

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "liby2oracle.so")
 REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
 
 KINDS = ["convolutional", "maxpool", "route", "reorg", "region", "avgpool", "softmax", "cost", "shortcut", "connected", "dropout",
-         "detection"]
+         "detection", "crop", "local", "batchnorm"]
 
 
 def build(force: bool = False) -> str:

@@ -29,7 +29,7 @@
 #include <time.h>
 
 enum { ORC_CONV = 0, ORC_MAXPOOL, ORC_ROUTE, ORC_REORG, ORC_REGION, ORC_AVGPOOL, ORC_SOFTMAX, ORC_COST, ORC_SHORTCUT,
-       ORC_CONNECTED, ORC_DROPOUT, ORC_DETECTION };
+       ORC_CONNECTED, ORC_DROPOUT, ORC_DETECTION, ORC_CROP, ORC_LOCAL, ORC_BATCHNORM };
 enum { ACT_LOGISTIC = 0, ACT_RELU, ACT_LINEAR, ACT_LEAKY, ACT_RAMP, ACT_TANH, ACT_ELU, ACT_HARDTAN };
 
 typedef struct {
@@ -54,6 +54,7 @@ typedef struct {
     int reverse;
     int classes, coords, softmax, classfix;
     int side, sqrt_;   /* [detection] */
+    int noadjust;      /* [crop] */
     int groups;
     float temperature;
     int dontload, dontloadscales;
@@ -449,6 +450,49 @@ orc_net *orc_parse_cfg(const char *path)
             l->outputs = w * h * c;
             l->inputs = l->outputs;
             l->activation = activation_from_name(opt(s, "activation") ? opt(s, "activation") : "linear");
+        } else if (!strcmp(t, "[crop]")) {
+            /* parser.c:319-341, crop_layer.c:16-46: the inference forward is a centred window, optionally 2x-1 */
+            l->kind = ORC_CROP;
+            l->out_h = opt_int(s, "crop_height", 1);
+            l->out_w = opt_int(s, "crop_width", 1);
+            l->noadjust = opt_int(s, "noadjust", 0);
+            if (!(h && w && c)) { fprintf(stderr, "Layer before crop layer must output image.\n"); return NULL; }
+            l->h = h; l->w = w; l->c = c; l->out_c = c;
+            l->inputs = h * w * c;
+            l->outputs = l->out_h * l->out_w * l->out_c;
+        } else if (!strcmp(t, "[local]")) {
+            /* parser.c:118-137, local_layer.c:10-93: out = (in - (pad ? 1 : size)) / stride + 1; one filter bank per location */
+            l->kind = ORC_LOCAL;
+            l->n = opt_int(s, "filters", 1);
+            l->size = opt_int(s, "size", 1);
+            l->stride = opt_int(s, "stride", 1);
+            l->pad = opt_int(s, "pad", 0);
+            l->activation = activation_from_name(opt(s, "activation") ? opt(s, "activation") : "logistic");
+            if (!(h && w && c)) { fprintf(stderr, "Layer before local layer must output image.\n"); return NULL; }
+            l->h = h; l->w = w; l->c = c;
+            l->out_h = (h - (l->pad ? 1 : l->size)) / l->stride + 1;
+            l->out_w = (w - (l->pad ? 1 : l->size)) / l->stride + 1;
+            l->out_c = l->n;
+            l->outputs = l->out_h * l->out_w * l->out_c;
+            l->inputs = h * w * c;
+            l->weights = calloc((size_t)c * l->n * l->size * l->size * l->out_h * l->out_w, sizeof(float));
+            l->biases = calloc(l->outputs, sizeof(float));
+            { size_t need = (size_t)l->out_h * l->out_w * l->size * l->size * c; if (need > ws) ws = need; }
+            {   /* im2col_cpu derives its own column count (im2col.c:20-21); the layer is only meaningful when both agree */
+                int hc = (h + 2 * l->pad - l->size) / l->stride + 1, wc = (w + 2 * l->pad - l->size) / l->stride + 1;
+                if (hc != l->out_h || wc != l->out_w) { fprintf(stderr, "oracle: [local] size/pad combination with mismatched im2col grid\n"); return NULL; }
+            }
+        } else if (!strcmp(t, "[batchnorm]")) {
+            /* parser.c:409-413, batchnorm_layer.c:5-57 */
+            int k;
+            l->kind = ORC_BATCHNORM;
+            l->h = l->out_h = h; l->w = l->out_w = w; l->c = l->out_c = c;
+            l->inputs = l->outputs = h * w * c;
+            l->n = c;
+            l->scales = calloc(c, sizeof(float));
+            for (k = 0; k < c; ++k) l->scales[k] = 1;
+            l->rolling_mean = calloc(c, sizeof(float));
+            l->rolling_variance = calloc(c, sizeof(float));
         } else {
             fprintf(stderr, "oracle: layer type %s is outside the hot path\n", t);
             return NULL;
@@ -506,6 +550,17 @@ int orc_load_weights(orc_net *net, const char *path)
                 got += fread(l->rolling_mean, sizeof(float), l->outputs, fp);
                 got += fread(l->rolling_variance, sizeof(float), l->outputs, fp);
             }
+            continue;
+        }
+        if (l->kind == ORC_BATCHNORM) {          /* parser.c:921-931 */
+            got += fread(l->scales, sizeof(float), l->c, fp);
+            got += fread(l->rolling_mean, sizeof(float), l->c, fp);
+            got += fread(l->rolling_variance, sizeof(float), l->c, fp);
+            continue;
+        }
+        if (l->kind == ORC_LOCAL) {              /* parser.c:1068-1078 */
+            got += fread(l->biases, sizeof(float), l->outputs, fp);
+            got += fread(l->weights, sizeof(float), (size_t)l->size * l->size * l->c * l->n * l->out_h * l->out_w, fp);
             continue;
         }
         if (l->kind != ORC_CONV) continue;
@@ -804,6 +859,35 @@ float *orc_predict(orc_net *net, const float *input)
                     float *pc = l->output + (size_t)b * l->inputs + (size_t)loc * l->classes;
                     orc_softmax(pc, l->classes, 1, pc);
                 }
+        } break;
+        case ORC_CROP: {           /* crop_layer.c:69-105 with !state.train: no flip, centred window, x*2-1 unless noadjust */
+            int dh = (l->h - l->out_h) / 2, dw = (l->w - l->out_w) / 2, ch, y, x;
+            float scale = l->noadjust ? 1 : 2, trans = l->noadjust ? 0 : -1;
+            size_t count = 0;
+            for (b = 0; b < l->batch; ++b) for (ch = 0; ch < l->c; ++ch) for (y = 0; y < l->out_h; ++y) for (x = 0; x < l->out_w; ++x)
+                l->output[count++] = cur[(x + dw) + (size_t)l->w * ((y + dh) + (size_t)l->h * (ch + (size_t)l->c * b))] * scale + trans;
+        } break;
+        case ORC_LOCAL: {          /* local_layer.c:95-126: bias copy, per image im2col, per location gemm_nn(n x 1 x k), activation */
+            int locations = l->out_h * l->out_w, kdim = l->size * l->size * l->c, j;
+            size_t e;
+            for (b = 0; b < l->batch; ++b) memcpy(l->output + (size_t)b * l->outputs, l->biases, (size_t)l->outputs * sizeof(float));
+            for (b = 0; b < l->batch; ++b) {
+                float *out = l->output + (size_t)b * l->outputs;
+                im2col(cur + (size_t)b * l->w * l->h * l->c, l->c, l->h, l->w, l->size, l->stride, l->pad, net->workspace);
+#pragma omp parallel for
+                for (j = 0; j < locations; ++j)
+                    gemm_rows(l->n, 1, kdim, l->weights + (size_t)j * kdim * l->n, kdim, net->workspace + j, locations, out + j, locations);
+            }
+            for (e = 0; e < (size_t)l->outputs * l->batch; ++e) l->output[e] = act(l->output[e], l->activation);
+        } break;
+        case ORC_BATCHNORM: {      /* batchnorm_layer.c:122-146 (!train): copy, normalize_cpu (blas.c:115-126), scale_bias; no bias term */
+            int f, sp = l->out_h * l->out_w;
+            for (b = 0; b < l->batch; ++b) for (f = 0; f < l->c; ++f) {
+                const float *x = cur + ((size_t)b * l->c + f) * sp;
+                float *y = l->output + ((size_t)b * l->c + f) * sp;
+                int q;
+                for (q = 0; q < sp; ++q) { y[q] = (x[q] - l->rolling_mean[f]) / (sqrt(l->rolling_variance[f]) + .000001f); y[q] *= l->scales[f]; }
+            }
         } break;
         case ORC_SHORTCUT: {       /* shortcut_layer.c:38-43: copy, shortcut_cpu (blas.c:57-81), activate_array */
             const float *add = net->layers[l->n].output;

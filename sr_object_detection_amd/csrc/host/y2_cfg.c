@@ -482,6 +482,94 @@ static layer make_connected(list *o, shape p)
     return l;
 }
 
+/* parser.c:319-341 parse_crop + crop_layer.c:16-46.  At inference the layer is a centred window of the input,
+ * mapped to [-1,1] unless noadjust (crop_layer.c:69-105); flip/angle/saturation/exposure only act in training. */
+static layer make_crop(list *o, shape p)
+{
+    layer l;
+    memset(&l, 0, sizeof l);
+    l.type = CROP;
+    l.out_h = option_find_int(o, "crop_height", 1);
+    l.out_w = option_find_int(o, "crop_width", 1);
+    l.flip = option_find_int(o, "flip", 0);
+    l.angle = option_find_float(o, "angle", 0);
+    l.saturation = option_find_float(o, "saturation", 1);
+    l.exposure = option_find_float(o, "exposure", 1);
+    if (!(p.h && p.w && p.c)) { y2_fail("Layer before crop layer must output image."); return l; }
+    l.noadjust = option_find_int_quiet(o, "noadjust", 0);
+    l.shift = option_find_float(o, "shift", 0);
+    l.batch = p.batch;
+    l.h = p.h; l.w = p.w; l.c = p.c;
+    if (l.out_h <= 0 || l.out_w <= 0 || l.out_h > l.h || l.out_w > l.w) {
+        y2_fail("crop layer: a %d x %d window does not fit the %d x %d input", l.out_h, l.out_w, l.h, l.w);
+        return l;
+    }
+    l.scale = (float)l.out_h / l.h;
+    l.out_c = p.c;
+    l.inputs = l.w * l.h * l.c;
+    l.outputs = l.out_w * l.out_h * l.out_c;
+    fprintf(stderr, "Crop Layer: %d x %d -> %d x %d x %d image\n", l.h, l.w, l.out_h, l.out_w, l.c);
+    return l;
+}
+
+/* parser.c:118-137 parse_local + local_layer.c:10-93: a convolution whose filter bank differs per output location;
+ * weights [locations][filters][c*size*size], one bias per output value.  pad is a flag: out = (in - (pad ? 1 : size)) /
+ * stride + 1, while the taps come from im2col_cpu with `pad` pixels of zero padding (local_layer.c:107-108). */
+static layer make_local(list *o, shape p)
+{
+    layer l;
+    int hc, wc;
+    memset(&l, 0, sizeof l);
+    l.type = LOCAL;
+    l.n = option_find_int(o, "filters", 1);
+    l.size = option_find_int(o, "size", 1);
+    l.stride = option_find_int(o, "stride", 1);
+    l.pad = option_find_int(o, "pad", 0);
+    l.activation = activation_by_name(option_find_str(o, "activation", "logistic"));
+    if (!(p.h && p.w && p.c)) { y2_fail("Layer before local layer must output image."); return l; }
+    if (l.n <= 0 || l.size <= 0 || l.stride <= 0 || l.pad < 0) { y2_fail("bad local layer geometry"); return l; }
+    l.batch = p.batch;
+    l.h = p.h; l.w = p.w; l.c = p.c;
+    l.out_h = (l.h - (l.pad ? 1 : l.size)) / l.stride + 1;
+    l.out_w = (l.w - (l.pad ? 1 : l.size)) / l.stride + 1;
+    /* the reference multiplies an im2col matrix whose grid is (in + 2*pad - size)/stride + 1 as if it had out_h*out_w
+     * columns; only configurations where the two agree are meaningful */
+    hc = (l.h + 2 * l.pad - l.size) / l.stride + 1; wc = (l.w + 2 * l.pad - l.size) / l.stride + 1;
+    if (l.out_h <= 0 || l.out_w <= 0 || hc != l.out_h || wc != l.out_w) {
+        y2_fail("local layer: size=%d pad=%d stride=%d gives a %d x %d output but a %d x %d im2col grid", l.size, l.pad, l.stride,
+                l.out_h, l.out_w, hc, wc);
+        return l;
+    }
+    l.out_c = l.n;
+    l.outputs = l.out_h * l.out_w * l.out_c;
+    l.inputs = l.w * l.h * l.c;
+    l.weights = calloc((size_t)l.c * l.n * l.size * l.size * l.out_h * l.out_w, sizeof(float));
+    l.biases = calloc(l.outputs, sizeof(float));
+    if (!l.weights || !l.biases) { y2_fail("out of memory for local layer weights"); return l; }
+    fprintf(stderr, "Local Layer: %d x %d x %d image, %d filters -> %d x %d x %d image\n", l.h, l.w, l.c, l.n, l.out_h, l.out_w, l.n);
+    return l;
+}
+
+/* parser.c:409-413 parse_batchnorm + batchnorm_layer.c:5-57: a standalone normalisation over the input's channels
+ * (scales, rolling mean / variance; no bias) */
+static layer make_batchnorm(shape p)
+{
+    layer l;
+    int i;
+    memset(&l, 0, sizeof l);
+    l.type = BATCHNORM;
+    if (!(p.h && p.w && p.c)) { y2_fail("Layer before batchnorm layer must output image."); return l; }
+    l.batch = p.batch;
+    l.h = l.out_h = p.h; l.w = l.out_w = p.w; l.c = l.out_c = p.c;
+    l.inputs = l.outputs = p.w * p.h * p.c;
+    l.scales = calloc(l.c, sizeof(float));
+    for (i = 0; i < l.c; ++i) l.scales[i] = 1;
+    l.rolling_mean = calloc(l.c, sizeof(float));
+    l.rolling_variance = calloc(l.c, sizeof(float));
+    fprintf(stderr, "Batch Normalization Layer: %d x %d x %d image\n", l.w, l.h, l.c);
+    return l;
+}
+
 /* parser.c:389-397: at inference a no-op whose output IS the previous layer's (parser.c:658-661) */
 static layer make_dropout(list *o, shape p)
 {
@@ -752,6 +840,9 @@ network parse_network_cfg(char *filename)    /* parser.c:585-700 */
         else if (is_type(t, "[connected]", "[conn]")) l = make_connected(s->options, p);
         else if (is_type(t, "[dropout]", NULL)) l = make_dropout(s->options, p);
         else if (is_type(t, "[detection]", NULL)) l = make_detection(s->options, p);
+        else if (is_type(t, "[crop]", NULL)) l = make_crop(s->options, p);
+        else if (is_type(t, "[local]", NULL)) l = make_local(s->options, p);
+        else if (is_type(t, "[batchnorm]", NULL)) l = make_batchnorm(p);
         else if (is_type(t, "[region]", NULL)) l = make_region(s->options, p);
         else if (is_type(t, "[avgpool]", "[avg]")) l = make_avgpool(p);
         else if (is_type(t, "[softmax]", "[soft]")) { l = make_softmax(s->options, p); net.hierarchy = l.softmax_tree; }

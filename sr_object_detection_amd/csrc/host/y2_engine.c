@@ -272,6 +272,31 @@ static int upload_weights(network *net)
         float *wp, *b;
         int K, co, ci, kh, kw, f;
         const int w_half = (i > 0) && ld_of(&net->layers[i - 1])->out_half;   /* half input -> half weights */
+        if (l->type == BATCHNORM) {
+            double *r = (double *)(host + d->off_rinv);
+            memcpy(host + d->off_mean, l->rolling_mean, l->c * sizeof(float));
+            memcpy(host + d->off_scale, l->scales, l->c * sizeof(float));
+            for (f = 0; f < l->c; ++f) r[f] = 1.0 / (sqrt((double)l->rolling_variance[f]) + (double).000001f);
+            continue;
+        }
+        if (l->type == LOCAL) {
+            /* reference: weights [location][filter][c][kh][kw], biases [filter][location] (local_layer.c:100,111-121);
+             * kernel: weights [location][filter][kh][kw][c], biases [location][filter] */
+            const int locations = l->out_h * l->out_w, kk = l->size * l->size;
+            int loc, t;
+            K = kk * l->c;
+            wp = (float *)(host + d->off_w_packed);
+            b = (float *)(host + d->off_bias);
+            for (loc = 0; loc < locations; ++loc)
+                for (co = 0; co < l->n; ++co) {
+                    const float *src = l->weights + ((size_t)loc * l->n + co) * K;
+                    float *dst = wp + ((size_t)loc * l->n + co) * K;
+                    for (ci = 0; ci < l->c; ++ci)
+                        for (t = 0; t < kk; ++t) dst[(size_t)t * l->c + ci] = src[(size_t)ci * kk + t];
+                    b[(size_t)loc * l->n + co] = l->biases[(size_t)co * locations + loc];
+                }
+            continue;
+        }
         if (l->type != CONVOLUTIONAL && l->type != CONNECTED) continue;
         K = l->size * l->size * l->c;
         wp = (float *)(host + d->off_w_packed);
@@ -416,7 +441,7 @@ int y2_engine_build(network *net)
                 if (pd && pd->out_half) { y2_fail("fp16 mode: layer %d (%s) needs an fp32 producer (a convolutional or avgpool layer)", i, get_layer_string(l->type)); return -1; }
                 break;
             case COST: d->out_half = pd ? pd->out_half : 0; break;
-            case SHORTCUT: case CONNECTED: case DETECTION: case DROPOUT:
+            case SHORTCUT: case CONNECTED: case DETECTION: case DROPOUT: case CROP: case LOCAL: case BATCHNORM:
                 y2_fail("fp16 mode: layer %d (%s) has no half-precision kernel", i, get_layer_string(l->type)); return -1;
             default: break;
             }
@@ -455,12 +480,12 @@ int y2_engine_build(network *net)
                 d->out_ld = l->out_c;
             }
             break;
-        case SHORTCUT:
+        case SHORTCUT: case CROP: case LOCAL: case BATCHNORM:
             d->out_floats = (size_t)l->batch * l->out_h * l->out_w * l->out_c;
             HIPCALL(y2h_malloc((void **)&d->out_alloc, d->out_floats * sizeof(float)));
             d->out = d->out_alloc;
             d->out_ld = l->out_c;
-            d->kernel = "shortcut";
+            d->kernel = l->type == SHORTCUT ? "shortcut" : l->type == CROP ? "crop" : l->type == LOCAL ? (e->strict ? "local_ref" : "local") : "batchnorm";
             break;
         case ROUTE:
             d->kernel = "route(zero-copy)";
@@ -614,6 +639,21 @@ int y2_engine_build(network *net)
         const float *x; int ldx;
         size_t wbytes;
         int w_half;
+        if (l->type == BATCHNORM) {
+            d->off_mean = off; off = align_up(off + l->c * sizeof(float), 64);
+            d->off_scale = off; off = align_up(off + l->c * sizeof(float), 64);
+            d->off_rinv = off; off = align_up(off + l->c * sizeof(double), 64);
+            continue;
+        }
+        if (l->type == LOCAL) {
+            if (l->activation != LINEAR && l->activation != LEAKY && l->activation != LOGISTIC && l->activation != RELU) {
+                y2_fail("layer %d: activation %d is not implemented on the device", i, (int)l->activation);
+                return -1;
+            }
+            d->off_w_packed = off; off = align_up(off + (size_t)l->out_h * l->out_w * l->n * l->size * l->size * l->c * sizeof(float), 256);
+            d->off_bias = off; off = align_up(off + (size_t)l->outputs * sizeof(float), 64);
+            continue;
+        }
         if (l->type != CONVOLUTIONAL && l->type != CONNECTED) continue;
         if (l->activation != LINEAR && l->activation != LEAKY && l->activation != LOGISTIC && l->activation != RELU) {
             y2_fail("layer %d: activation %d is not implemented on the device", i, (int)l->activation);
@@ -821,6 +861,20 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
             HIPCALL(y2h_shortcut(x, ldx, fd->out, fd->out_ld, d->out, d->out_ld, l->batch, l->w, l->h, l->c,
                                  l->out_w, l->out_h, l->out_c, act, e->stream));
         } break;
+        case CROP:
+            HIPCALL(y2h_crop(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->out_h, l->out_w, l->noadjust, e->stream));
+            break;
+        case BATCHNORM:
+            HIPCALL(y2h_batchnorm(x, ldx, d->out, d->out_ld, (long)l->batch * l->h * l->w, l->c, (const float *)(e->arena + d->off_mean),
+                                  (const double *)(e->arena + d->off_rinv), (const float *)(e->arena + d->off_scale), e->stream));
+            break;
+        case LOCAL: {
+            int act = l->activation == LEAKY ? Y2H_ACT_LEAKY : l->activation == LOGISTIC ? Y2H_ACT_LOGISTIC :
+                      l->activation == RELU ? Y2H_ACT_RELU : Y2H_ACT_LINEAR;
+            HIPCALL(y2h_local(x, ldx, (const float *)(e->arena + d->off_w_packed), (const float *)(e->arena + d->off_bias), d->out,
+                              d->out_ld, l->batch, l->h, l->w, l->c, l->n, l->size, l->stride, l->pad, l->out_h, l->out_w, act,
+                              e->strict, e->stream));
+        } break;
         case COST:
             break;                    /* cost_layer.c:75: nothing happens without truth */
         default:
@@ -1026,6 +1080,13 @@ int resize_network(network *net, int w, int h)   /* network.c:322-388 */
             l->out_h = (h + 2 * l->pad) / l->stride;
             l->outputs = l->out_w * l->out_h * l->c;
             break;
+        case CROP:                           /* crop_layer.c:48-66 */
+            l->w = w; l->h = h;
+            l->out_w = l->scale * w;
+            l->out_h = l->scale * h;
+            l->inputs = l->w * l->h * l->c;
+            l->outputs = l->out_h * l->out_w * l->out_c;
+            break;
         case REGION:                         /* region_layer.c:53-71 */
             l->w = w; l->h = h;
             l->outputs = h * w * l->n * (l->classes + l->coords + 1);
@@ -1116,6 +1177,9 @@ char *get_layer_string(LAYER_TYPE a)         /* network.c:73-130 */
     case SOFTMAX: return "softmax";
     case COST: return "cost";
     case SHORTCUT: return "shortcut";
+    case CROP: return "crop";
+    case LOCAL: return "local";
+    case BATCHNORM: return "batchnorm";
     case CONNECTED: return "connected";
     case DROPOUT: return "dropout";
     case DETECTION: return "detection";

@@ -68,6 +68,18 @@ void load_weights_upto(network *net, char *filename, int cutoff)
             }
             continue;
         }
+        if (l->type == BATCHNORM) {                  /* parser.c:921-931 load_batchnorm_weights */
+            if (fread(l->scales, sizeof(float), l->c, fp) != (size_t)l->c) break;
+            if (fread(l->rolling_mean, sizeof(float), l->c, fp) != (size_t)l->c) break;
+            if (fread(l->rolling_variance, sizeof(float), l->c, fp) != (size_t)l->c) break;
+            continue;
+        }
+        if (l->type == LOCAL) {                      /* parser.c:1068-1078 */
+            num = (size_t)l->size * l->size * l->c * l->n * l->out_w * l->out_h;
+            if (fread(l->biases, sizeof(float), l->outputs, fp) != (size_t)l->outputs) break;
+            if (fread(l->weights, sizeof(float), num, fp) != num) break;
+            continue;
+        }
         if (l->type != CONVOLUTIONAL) continue;
         num = (size_t)l->n * l->c * l->size * l->size;
         /* short reads leave the remaining values untouched, as in the reference */
@@ -110,6 +122,17 @@ void save_weights_upto(network net, char *filename, int cutoff)
                 fwrite(l->rolling_mean, sizeof(float), l->outputs, fp);
                 fwrite(l->rolling_variance, sizeof(float), l->outputs, fp);
             }
+            continue;
+        }
+        if (l->type == BATCHNORM) {                  /* parser.c:794-804 save_batchnorm_weights */
+            fwrite(l->scales, sizeof(float), l->c, fp);
+            fwrite(l->rolling_mean, sizeof(float), l->c, fp);
+            fwrite(l->rolling_variance, sizeof(float), l->c, fp);
+            continue;
+        }
+        if (l->type == LOCAL) {                      /* parser.c:865-875 */
+            fwrite(l->biases, sizeof(float), l->outputs, fp);
+            fwrite(l->weights, sizeof(float), (size_t)l->size * l->size * l->c * l->n * l->out_w * l->out_h, fp);
             continue;
         }
         if (l->type != CONVOLUTIONAL) continue;

@@ -384,3 +384,214 @@ extern "C" int y2h_shortcut(const float *in, int ld_in, const float *add, int ld
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }
+
+// ---------------------------------------------------------------------------
+// [crop] at inference (crop_layer.c:69-105 with !state.train): the centred out_h x out_w window of every image,
+// each value mapped x*scale + trans (2, -1 unless noadjust).  NHWC in, NHWC out; one thread per value.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy, int h, int w,
+                                                   int c, int oh, int ow, int dh, int dw, float scale, float trans, long total)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % c);
+        const long pix = idx / c;
+        const int ox = (int)(pix % ow);
+        const int oy = (int)((pix / ow) % oh);
+        const long b = pix / ((long)ow * oh);
+        const float v = x[((b * h + oy + dh) * w + ox + dw) * ldx + k];
+        y[pix * ldy + k] = v * scale + trans;
+    }
+}
+
+extern "C" int y2h_crop(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c, int out_h, int out_w,
+                        int noadjust, y2h_stream s)
+{
+    if (!x || !y || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || out_h <= 0 || out_w <= 0 || out_h > h || out_w > w) return Y2H_EINVAL;
+    if (ldx < c || ldy < c) return Y2H_EINVAL;
+    const long total = (long)batch * out_h * out_w * c;
+    hipLaunchKernelGGL(crop_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), x, ldx, y, ldy, h, w, c, out_h, out_w,
+                       (h - out_h) / 2, (w - out_w) / 2, noadjust ? 1.f : 2.f, noadjust ? 0.f : -1.f, total);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// standalone [batchnorm] at inference (batchnorm_layer.c:122-146): y = ((x - mean) / (sqrt(var) + 1e-6f)) * scale per
+// channel, the divide evaluated in double as in blas.c:122 (rinv = 1 / (sqrt(var) + 1e-6f) prepared in double).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void batchnorm_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy, int c,
+                                                        const float *__restrict__ mean, const double *__restrict__ rinv,
+                                                        const float *__restrict__ scale, long total)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % c);
+        const long pix = idx / c;
+        const float d = x[pix * ldx + k] - mean[k];
+        float v = (float)((double)d * rinv[k]);
+        y[pix * ldy + k] = v * scale[k];
+    }
+}
+
+extern "C" int y2h_batchnorm(const float *x, int ldx, float *y, int ldy, long pixels, int c, const float *mean, const double *rinv,
+                             const float *scale, y2h_stream s)
+{
+    if (!x || !y || !mean || !rinv || !scale || pixels <= 0 || c <= 0 || ldx < c || ldy < c) return Y2H_EINVAL;
+    const long total = pixels * c;
+    hipLaunchKernelGGL(batchnorm_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), x, ldx, y, ldy, c, mean, rinv, scale, total);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// [local] (local_layer.c:95-126): a convolution with a separate filter bank per output location.  Every weight is
+// used once per image, so the layer streams its weights from HBM (yolov1/yolo.cfg: 49 x 256 x 9216 floats = 462 MB):
+// one wave owns (location, 4 filters), lanes stride over the K = size*size*c taps with 16-byte loads of the weights
+// (re-ordered at upload to [location][filter][kh][kw][c], matching the NHWC activations) and of the input, up to
+// four images per pass so the weights are read once per four images; a wave reduction finishes the dot products.
+//   y = act(bias + sum_k w*x)         (the reference adds the bias first; same value to rounding)
+// local_ref_kernel is the strict-mode form: one thread per output value, bias first, taps in the reference's
+// k = (c, kh, kw) order, product and sum rounded separately -- the arithmetic of gemm_nn (gemm.c:74-88).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float activate_ref(float v, int act)
+{
+    if (act == Y2H_ACT_LEAKY) v = (v > 0) ? v : (float)(.1 * (double)v);
+    else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));
+    else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);
+    return v;
+}
+
+struct LocalK {
+    const float *x; int ldx;
+    const float *wp;            // [loc][n][kh][kw][c]
+    const float *bias;          // [loc][n]
+    float *y; int ldy;
+    int batch, h, w, c, n, size, stride, pad, oh, ow, act;
+};
+
+template <int NB, bool VEC>
+__global__ __launch_bounds__(256) void local_kernel(LocalK a)
+{
+    const int lane = threadIdx.x & 63;
+    const int groups = (a.n + 3) >> 2;
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long nwork = (long)a.oh * a.ow * groups;
+    if (wave >= nwork) return;
+    const int loc = (int)(wave / groups), m0 = (int)(wave - (long)loc * groups) * 4;
+    const int oy = loc / a.ow, ox = loc - oy * a.ow;
+    const int K = a.size * a.size * a.c;
+    const float *w0 = a.wp + ((size_t)loc * a.n + m0) * K;
+    const int nf = (a.n - m0 < 4) ? a.n - m0 : 4;
+    for (int b0 = 0; b0 < a.batch; b0 += NB) {
+        float acc[NB][4];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        constexpr int STEP = VEC ? 4 : 1;
+        for (int k = lane * STEP; k < K; k += 64 * STEP) {
+            const int tap = k / a.c, ci = k - tap * a.c;
+            const int kh = tap / a.size, kw = tap - kh * a.size;
+            const int iy = oy * a.stride + kh - a.pad, ix = ox * a.stride + kw - a.pad;
+            const bool in = iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+            float wv[4][STEP];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nf) {
+                    if constexpr (VEC) { const float4 t = *(const float4 *)(w0 + (size_t)j * K + k); wv[j][0] = t.x; wv[j][1] = t.y; wv[j][2] = t.z; wv[j][3] = t.w; }
+                    else wv[j][0] = w0[(size_t)j * K + k];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < STEP; ++q) wv[j][q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                float xv[STEP];
+#pragma unroll
+                for (int q = 0; q < STEP; ++q) xv[q] = 0.f;
+                if (in && b0 + i < a.batch) {
+                    const float *xp = a.x + (((size_t)(b0 + i) * a.h + iy) * a.w + ix) * a.ldx + ci;
+                    if constexpr (VEC) { const float4 t = *(const float4 *)xp; xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w; }
+                    else xv[0] = *xp;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < STEP; ++q) acc[i][j] = __builtin_fmaf(wv[j][q], xv[q], acc[i][j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[i][j];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                acc[i][j] = v;
+            }
+        if (lane < 4 && lane < nf) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (b0 + i >= a.batch) break;
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v = (lane == j) ? acc[i][j] : v;
+                v = a.bias[(size_t)loc * a.n + m0 + lane] + v;
+                a.y[((size_t)(b0 + i) * a.oh * a.ow + loc) * a.ldy + m0 + lane] = activate_ref(v, a.act);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void local_ref_kernel(LocalK a)
+{
+    const long total = (long)a.batch * a.oh * a.ow * a.n;
+    const int K = a.size * a.size * a.c;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int m = (int)(idx % a.n);
+        const long r = idx / a.n;
+        const int loc = (int)(r % ((long)a.oh * a.ow));
+        const long b = r / ((long)a.oh * a.ow);
+        const int oy = loc / a.ow, ox = loc - oy * a.ow;
+        const float *wr = a.wp + ((size_t)loc * a.n + m) * K;
+        float v = a.bias[(size_t)loc * a.n + m];
+        for (int ci = 0; ci < a.c; ++ci)
+            for (int kh = 0; kh < a.size; ++kh)
+                for (int kw = 0; kw < a.size; ++kw) {
+                    const int iy = oy * a.stride + kh - a.pad, ix = ox * a.stride + kw - a.pad;
+                    const float xv = (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) ? a.x[((b * a.h + iy) * a.w + ix) * a.ldx + ci] : 0.f;
+                    const float p = wr[(kh * a.size + kw) * a.c + ci] * xv;
+                    v = v + p;
+                }
+        a.y[(b * a.oh * a.ow + loc) * a.ldy + m] = activate_ref(v, a.act);
+    }
+}
+
+extern "C" int y2h_local(const float *x, int ldx, const float *w_packed, const float *bias_packed, float *y, int ldy, int batch,
+                         int h, int w, int c, int n, int size, int stride, int pad, int out_h, int out_w, int activation,
+                         int strict, y2h_stream s)
+{
+    if (!x || !w_packed || !bias_packed || !y || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || n <= 0 || size <= 0 || stride <= 0 ||
+        pad < 0 || out_h <= 0 || out_w <= 0 || ldx < c || ldy < n) return Y2H_EINVAL;
+    if ((out_h - 1) * stride + size - pad > h + pad || (out_w - 1) * stride + size - pad > w + pad) return Y2H_EINVAL;
+    LocalK a;
+    a.x = x; a.ldx = ldx; a.wp = w_packed; a.bias = bias_packed; a.y = y; a.ldy = ldy; a.batch = batch; a.h = h; a.w = w; a.c = c;
+    a.n = n; a.size = size; a.stride = stride; a.pad = pad; a.oh = out_h; a.ow = out_w; a.act = activation;
+    if (strict) {
+        hipLaunchKernelGGL(local_ref_kernel, dim3(y2h_grid((long)batch * out_h * out_w * n, 256)), dim3(256), 0, S(s), a);
+        Y2H_LAUNCH_CHECK();
+        return Y2H_OK;
+    }
+    const long waves = (long)out_h * out_w * ((n + 3) / 4);
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const bool vec = (c % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)x | (uintptr_t)w_packed) % 16 == 0);
+    if (batch == 1) {
+        if (vec) hipLaunchKernelGGL((local_kernel<1, true>), dim3(blocks), dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL((local_kernel<1, false>), dim3(blocks), dim3(256), 0, S(s), a);
+    } else {
+        if (vec) hipLaunchKernelGGL((local_kernel<4, true>), dim3(blocks), dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL((local_kernel<4, false>), dim3(blocks), dim3(256), 0, S(s), a);
+    }
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}

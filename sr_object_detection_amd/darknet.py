@@ -76,6 +76,8 @@ class Layer(C.Structure):    # include/sr_yolo2.h struct layer
         ("output", C.POINTER(C.c_float)), ("delta", C.POINTER(C.c_float)), ("cost", C.POINTER(C.c_float)),
         ("workspace_size", C.c_size_t), ("dev", C.c_void_p),
         ("side", C.c_int), ("forced", C.c_int), ("probability", C.c_float),
+        ("flip", C.c_int), ("noadjust", C.c_int), ("angle", C.c_float), ("saturation", C.c_float),
+        ("exposure", C.c_float), ("shift", C.c_float),
     ]
 
 

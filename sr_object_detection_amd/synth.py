@@ -119,6 +119,20 @@ def write_weights(path: str, layers, seed: int, head_gain: float = 4.0, version=
                     f.write(uniform(s + 2, n, 0.8, 1.2).tobytes())
                     f.write(uniform(s + 3, n, -0.1, 0.1).tobytes())
                     f.write(uniform(s + 4, n, 0.5, 1.5).tobytes())
+            elif l["type"] == "batchnorm":
+                # parser.c:794-804 order: scales, rolling_mean, rolling_variance (no biases)
+                n = l["c"]
+                s = seed * 1000003 + 600000 + li * 7919
+                f.write(uniform(s + 2, n, 0.8, 1.2).tobytes())
+                f.write(uniform(s + 3, n, -0.1, 0.1).tobytes())
+                f.write(uniform(s + 4, n, 0.5, 1.5).tobytes())
+            elif l["type"] == "local":
+                # parser.c:865-875 order: biases [outputs], weights [locations][filters][c*size*size]
+                K = l["size"] * l["size"] * l["c"]
+                s = seed * 1000003 + 700000 + li * 7919
+                a = math.sqrt(6.0 / K)
+                f.write(uniform(s + 1, l["outputs"], -0.1, 0.1).tobytes())
+                f.write(uniform(s + 5, l["out_w"] * l["out_h"] * l["filters"] * K, -a, a).tobytes())
         return f.tell()
 
 

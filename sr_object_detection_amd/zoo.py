@@ -18,6 +18,7 @@ from __future__ import annotations
 #   ("conv", filters, size, bn, activation)      stride 1, pad=1
 #   ("max", size, stride) | ("route", [idx...]) | ("reorg", stride)
 #   ("region", dict) | ("avg",) | ("softmax",) | ("cost",)
+#   ("crop", width, height, noadjust) | ("batchnorm",) | ("local", filters, size, stride, pad, activation)
 
 _D19_TRUNK = [
     ("conv", 32, 3, 1, "leaky"), ("max", 2, 2),
@@ -103,7 +104,29 @@ SPECS["mini-v1"] = [
     ("detection", {"classes": 5, "num": 2, "side": 4, "softmax": 1, "sqrt": 1}),
 ]
 
-DEFAULT_SIZE = {"yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32, "tiny-yolo-v1": 448, "mini-v1": 32}
+# the remaining YOLOv1-era layer types (cfg/yolov1/yolo.cfg, yolo-small.cfg, xyolo.test.cfg): [crop] (centred window,
+# 2x-1), a standalone [batchnorm], a locally connected layer with and without padding, then the dense head
+SPECS["mini-v1-local"] = [
+    ("crop", 32, 32, 0), ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("batchnorm",), ("conv", 32, 3, 1, "leaky"), ("max", 2, 2),
+    ("local", 24, 3, 1, 1, "leaky"), ("local", 8, 3, 1, 0, "logistic"), ("dropout", 0.5), ("connected", 240, 0, "linear"),
+    ("detection", {"classes": 5, "num": 2, "side": 4, "softmax": 1, "sqrt": 1}),
+]
+
+# cfg/yolov1/yolo.cfg: the full YOLOv1 -- 7x7/2 stem, 24 convolutions, a 3x3/2 convolution, a locally connected layer
+# (49 locations x 256 filters x 9216 taps = 462 MB of weights), dropout, one dense layer, the [detection] head
+SPECS["yolo-v1"] = [
+    ("conv", 64, 7, 1, "leaky", 2), ("max", 2, 2), ("conv", 192, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 128, 1, 1, "leaky"), ("conv", 256, 3, 1, "leaky"), ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"), ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"),
+    ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"), ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"),
+    ("conv", 512, 1, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 512, 1, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"), ("conv", 512, 1, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"),
+    ("conv", 1024, 3, 1, "leaky"), ("conv", 1024, 3, 1, "leaky", 2), ("conv", 1024, 3, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"),
+    ("local", 256, 3, 1, 1, "leaky"), ("dropout", 0.5), ("connected", 1715, 0, "linear"),
+    ("detection", {"classes": 20, "num": 3, "side": 7, "softmax": 0, "sqrt": 1}),
+]
+
+DEFAULT_SIZE = {"yolo-v1": 448, "mini-v1-local": 40, "yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32, "tiny-yolo-v1": 448, "mini-v1": 32}
 
 
 def cfg_text(name: str, width: int | None = None, height: int | None = None, batch: int = 1,
@@ -149,6 +172,13 @@ def cfg_text(name: str, width: int | None = None, height: int | None = None, bat
             d = e[1]
             out += ["[detection]", "classes=%d" % d["classes"], "coords=4", "rescore=1", "side=%d" % d["side"],
                     "num=%d" % d["num"], "softmax=%d" % d.get("softmax", 0), "sqrt=%d" % d.get("sqrt", 1), "jitter=.2", ""]
+        elif kind == "crop":
+            out += ["[crop]", "crop_width=%d" % e[1], "crop_height=%d" % e[2], "flip=0", "angle=0", "saturation=1", "exposure=1",
+                    "noadjust=%d" % e[3], ""]
+        elif kind == "batchnorm":
+            out += ["[batchnorm]", ""]
+        elif kind == "local":
+            out += ["[local]", "filters=%d" % e[1], "size=%d" % e[2], "stride=%d" % e[3], "pad=%d" % e[4], "activation=%s" % e[5], ""]
         elif kind == "avg":
             out += ["[avgpool]", ""]
         elif kind == "softmax":
@@ -204,6 +234,14 @@ def resolve(name_or_spec, width: int, height: int | None = None, channels: int =
             d = e[1]
             L.update(type="detection", classes=d["classes"], num=d["num"], side=d["side"], softmax=d.get("softmax", 0),
                      sqrt=d.get("sqrt", 1), out_w=0, out_h=0, out_c=0, outputs=inputs)
+        elif kind == "crop":
+            L.update(type="crop", noadjust=e[3], out_w=e[1], out_h=e[2], out_c=c)
+        elif kind == "batchnorm":
+            L.update(type="batchnorm", out_w=w, out_h=h, out_c=c)
+        elif kind == "local":
+            _, filters, size, stride, pad, act = e
+            L.update(type="local", filters=filters, size=size, stride=stride, pad=pad, activation=act,
+                     out_w=(w - (1 if pad else size)) // stride + 1, out_h=(h - (1 if pad else size)) // stride + 1, out_c=filters)
         elif kind == "avg":
             L.update(type="avgpool", out_w=1, out_h=1, out_c=c)
         elif kind in ("softmax", "cost"):

@@ -159,7 +159,7 @@ def test_errors_are_loud(workdir):
     with pytest.raises(darknet.Y2Error):
         darknet.Network.parse_network_cfg(os.path.join(workdir, "does_not_exist.cfg"))
     bad = os.path.join(workdir, "bad.cfg")
-    open(bad, "w").write("[net]\nbatch=1\nwidth=32\nheight=32\nchannels=3\n\n[local]\nfilters=10\n")
+    open(bad, "w").write("[net]\nbatch=1\nwidth=32\nheight=32\nchannels=3\n\n[gru]\nfilters=10\n")
     with pytest.raises(darknet.Y2Error, match="outside"):
         darknet.Network.parse_network_cfg(bad)
     cfg, wts, x = materialize(workdir, "mini", 32, 1, 5)

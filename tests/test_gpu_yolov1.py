@@ -1,5 +1,7 @@
 """YOLOv1 family: [connected] [dropout] [detection] + get_detection_boxes on the GPU against the golden
-vectors the compiled reference produced (tests/golden/mini_v1_32_b2.npz, tiny_yolo_v1_448_b1.npz).
+vectors the compiled reference produced (tests/golden/mini_v1_32_b2.npz, tiny_yolo_v1_448_b1.npz), and the older layer
+types of cfg/yolov1/yolo.cfg, yolo-small.cfg and xyolo.test.cfg -- [crop], [local], standalone [batchnorm]
+(mini_v1_local_40_b2.npz).
 
 The dense layers run as 1x1 convolutions on the matrix cores with their weights re-ordered for the NHWC producer;
 strict mode uses the reference-order kernel and must be bit-identical, decode and NMS included."""
@@ -12,7 +14,7 @@ from tests.helpers import dense_from_sparse, load_golden, materialize
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-CASES = ["mini_v1_32_b2", "tiny_yolo_v1_448_b1"]
+CASES = ["mini_v1_32_b2", "tiny_yolo_v1_448_b1", "mini_v1_local_40_b2"]
 
 
 def _open(workdir, name):
@@ -29,8 +31,11 @@ def test_forward_decode_nms_match_reference_golden(workdir, name):
     out = net.network_predict(x)
     assert out.shape == g["out"].shape and np.abs(out - g["out"]).max() < TOL
     kinds = [net.layer_kernel(i) for i in range(net.n)]
-    assert any(k.startswith("conv_mfma_f32") and darknet.LAYER_TYPES[net.layer(i).type] == "CONNECTED"
-               for i, k in enumerate(kinds)), kinds
+    if name == "mini_v1_local_40_b2":
+        assert {"crop", "batchnorm", "local"} <= set(kinds), kinds
+    else:
+        assert any(k.startswith("conv_mfma_f32") and darknet.LAYER_TYPES[net.layer(i).type] == "CONNECTED"
+                   for i, k in enumerate(kinds)), kinds
     thresh, nms = float(g["thresh"]), float(g["nms"])
     l = net.last
     total, classes = l.side * l.side * l.n, l.classes
@@ -54,13 +59,15 @@ def test_forward_decode_nms_match_reference_golden(workdir, name):
     net.free()
 
 
-@pytest.mark.parametrize("name", ["mini_v1_32_b2"])
+@pytest.mark.parametrize("name", ["mini_v1_32_b2", "mini_v1_local_40_b2"])
 def test_strict_mode_is_bit_identical(workdir, name):
     g, net, x = _open(workdir, name)
     net.set_strict(True)
     out = net.network_predict(x)
     assert np.array_equal(out, g["out"])
     assert any(net.layer_kernel(i) == "connected_ref" for i in range(net.n))
+    if name == "mini_v1_local_40_b2":
+        assert any(net.layer_kernel(i) == "local_ref" for i in range(net.n))
     thresh, nms = float(g["thresh"]), float(g["nms"])
     l = net.last
     total, classes = l.side * l.side * l.n, l.classes
@@ -73,15 +80,47 @@ def test_strict_mode_is_bit_identical(workdir, name):
     net.free()
 
 
-def test_every_layer_of_mini_v1_against_oracle(oracle, workdir):
-    g, net, x = _open(workdir, "mini_v1_32_b2")
+@pytest.mark.parametrize("name", ["mini_v1_32_b2", "mini_v1_local_40_b2"])
+def test_every_layer_of_mini_v1_against_oracle(oracle, workdir, name):
+    g, net, x = _open(workdir, name)
     net.set_fusion(False)
     net.network_predict(x)
-    cfg, wts, _ = materialize(workdir, "mini-v1", 32, 2, int(g["seed"]), float(g["head_gain"]))
+    cfg, wts, _ = materialize(workdir, str(g["net"]), int(g["size"]), int(g["batch"]), int(g["seed"]), float(g["head_gain"]))
     on = oracle.OracleNet(cfg, wts)
     on.predict(x)
     for i in range(net.n):
         got, want = net.pull_layer_output(i), on.layer_output(i)
         assert np.abs(got - want).max() < TOL * max(1.0, float(np.abs(want).max())), (i, net.layer_kernel(i))
+    net.free()
+    on.close()
+
+
+@pytest.mark.parametrize("batch", [1, 3, 5])
+def test_local_layer_batches_and_unaligned_channels(oracle, workdir, batch):
+    """[local] with c % 4 != 0 (scalar tap loads), a filter count that is not a multiple of 4, stride 2, and batches on
+    either side of the four-images-per-pass blocking."""
+    from sr_object_detection_amd import synth, zoo
+    import os
+    spec = [("conv", 6, 3, 1, "leaky"), ("local", 7, 3, 2, 1, "leaky"), ("local", 5, 2, 1, 0, "relu"), ("connected", 36, 0, "linear"),
+            ("detection", {"classes": 4, "num": 1, "side": 2, "softmax": 0, "sqrt": 0})]
+    cfg = os.path.join(workdir, "loc.cfg")
+    with open(cfg, "w") as f:
+        f.write(zoo.cfg_text("loc", 12, 12, batch, spec=spec))
+    wts = os.path.join(workdir, "loc.weights")
+    synth.write_weights(wts, zoo.resolve(spec, 12), 5, 1.0)
+    x = synth.image_batch(batch, 3, 12, 12, seed=77)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    on = oracle.OracleNet(cfg, wts)
+    on.predict(x)
+    for strict in (False, True):
+        net.set_strict(strict)
+        net.network_predict(x)
+        for i in range(net.n):
+            got, want = net.pull_layer_output(i), on.layer_output(i)
+            if strict:
+                assert np.array_equal(got, want), (i, net.layer_kernel(i))
+            else:
+                assert np.abs(got - want).max() < TOL * max(1.0, float(np.abs(want).max())), (i, net.layer_kernel(i))
     net.free()
     on.close()
