@@ -79,9 +79,9 @@ int         y2h_event_elapsed_ms(y2h_event start, y2h_event stop, float *ms);   
 /* [n][c][h][w] -> [n][h][w][ld] (channels 0..c-1 of each pixel row) and back */
 int y2h_nchw_to_nhwc(const float *src, float *dst, int n, int c, int h, int w, int ld, y2h_stream s);
 int y2h_nhwc_to_nchw(const float *src, int ld, float *dst, int n, int c, int h, int w, y2h_stream s);
-/* [n][c][h][w] -> interior of [n][h+2][w+2][ld]; the one-pixel border is not written
+/* [n][c][h][w] -> interior of [n][h+2*halo][w+2*halo][ld]; the border is not written
  * (the caller zeroes the buffer once) */
-int y2h_nchw_to_nhwc_halo(const float *src, float *dst, int n, int c, int h, int w, int ld, y2h_stream s);
+int y2h_nchw_to_nhwc_halo(const float *src, float *dst, int n, int c, int h, int w, int ld, int halo, y2h_stream s);
 /* copy `c` channels of `npix` pixels between two NHWC buffers ([route] fallback) */
 int y2h_copy_channels(const float *src, int ld_src, float *dst, int ld_dst, int c, long npix, y2h_stream s);
 
@@ -89,8 +89,8 @@ int y2h_copy_channels(const float *src, int ld_src, float *dst, int ld_dst, int 
 typedef struct y2h_conv {
     int batch, h, w, c;          /* input  NHWC dims                                   */
     int ldx;                     /* input  channel stride (floats)                     */
-    int x_halo;                  /* 0, or 1: x is [batch][h+2][w+2][ldx] with a zero border
-                                    (layout of y2h_nchw_to_nhwc_halo; first-layer kernel only) */
+    int x_halo;                  /* 0, or p > 0: x is [batch][h+2p][w+2p][ldx] with a zero border of p pixels
+                                    (layout of y2h_nchw_to_nhwc_halo; first-layer / stem kernels only) */
     int n;                       /* filters (output channels)                          */
     int size, stride, pad;       /* square kernel                                      */
     int out_h, out_w;
@@ -126,6 +126,10 @@ size_t y2h_conv_workspace_bytes(const y2h_conv *d);
 /* 1 when the shape fits the dedicated first-layer kernel (3 channels, 3x3/1 pad 1, <= 64
  * filters) provided the input is supplied with a halo (x_halo = 1) */
 int y2h_conv_first_layer_ok(const y2h_conv *d);
+/* halo width (>= 0) the few-channel stem kernel wants for this shape (any size / stride with pad as the halo, c <= 4,
+ * <= 128 filters: the 7x7/2 stems of cfg/yolov1/yolo.cfg, resnet50.cfg, extraction.cfg), or -1 when the shape does
+ * not fit it; pass the descriptor back with x_halo set to that value */
+int y2h_conv_stem_halo(const y2h_conv *d);
 /* same for the fp16 first-layer kernel, whose input is [batch][h+2][w+2][4] halves (x_f16 = 1, ldx = 4,
  * layout of y2h_nchw_to_nhwc4_halo_f16) and whose weights stay the fp32 packed [n][27] */
 int y2h_conv_first_layer_f16_ok(const y2h_conv *d);

@@ -175,7 +175,7 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     default: c->activation = -1; break;
     }
     c->x = x;
-    c->x_halo = (i == 0) ? (e->in_halo != 0) : 0;       /* in_halo 2: half [b][h+2][w+2][4] for the fp16 first-layer kernel */
+    c->x_halo = (i == 0 && e->in_halo) ? e->in_halo_px : 0;   /* in_halo 2: half [b][h+2][w+2][4] for the fp16 first-layer kernel */
     c->fuse_maxpool2 = d->fused_pool;
     c->ws = e->d_ws;
     c->ws_bytes = e->ws_bytes;
@@ -552,12 +552,18 @@ int y2_engine_build(network *net)
         c0.size = l0->size; c0.stride = l0->stride; c0.pad = l0->pad; c0.out_h = l0->out_h; c0.out_w = l0->out_w;
         c0.w_packed = (const float *)(uintptr_t)256;
         e->in_halo = y2h_conv_first_layer_ok(&c0);
+        e->in_halo_px = 1;
+        if (!e->in_halo && !(e->half && ld_of(l0)->out_half)) {
+            /* other few-channel stems (7x7/2, 11x11/4, ...): the stem kernel reads a halo as wide as the padding */
+            const int px = y2h_conv_stem_halo(&c0);
+            if (px > 0) { e->in_halo = 1; e->in_halo_px = px; }
+        }
         /* fp16 mode: the first layer reads a half [b][h+2][w+2][4] copy of the input on the fp16 matrix cores */
         if (e->half && ld_of(l0)->out_half && net->c <= 4 && y2h_conv_first_layer_f16_ok(&c0)) e->in_halo = 2;
     }
     HIPCALL(y2h_malloc((void **)&e->d_in_nchw, e->in_floats * sizeof(float)));
     {
-        size_t nhwc = e->in_halo ? (size_t)net->batch * (net->h + 2) * (net->w + 2) * net->c : e->in_floats;
+        size_t nhwc = e->in_halo ? (size_t)net->batch * (net->h + 2 * e->in_halo_px) * (net->w + 2 * e->in_halo_px) * net->c : e->in_floats;
         if (e->in_halo == 2) nhwc = (size_t)net->batch * (net->h + 2) * (net->w + 2) * 2;   /* 4 halves = 2 floats per pixel */
         HIPCALL(y2h_malloc((void **)&e->d_in_nhwc, nhwc * sizeof(float)));
         HIPCALL(y2h_memset(e->d_in_nhwc, 0, nhwc * sizeof(float), e->stream));     /* the halo stays zero */
@@ -758,7 +764,7 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
     if (e->in_halo == 2)
         HIPCALL(y2h_nchw_to_nhwc4_halo_f16(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, e->stream));
     else if (e->in_halo)
-        HIPCALL(y2h_nchw_to_nhwc_halo(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));
+        HIPCALL(y2h_nchw_to_nhwc_halo(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->in_halo_px, e->stream));
     else
         HIPCALL(y2h_nchw_to_nhwc(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->stream));
     if (e->timing) HIPCALL(y2h_event_record(e->ev[0], e->stream));

@@ -46,7 +46,8 @@ typedef struct y2_engine {
     int timing;
     int fusion, built_fusion;  /* conv+maxpool fusion enabled / state of the current plan */
     int half, built_half;      /* fp16 storage requested (y2_set_half) / state of the current plan */
-    int in_halo;               /* the NHWC copy of the input carries a one-pixel zero border */
+    int in_halo;               /* the NHWC copy of the input carries a zero border (2: the half NHWC4 form) */
+    int in_halo_px;            /* its width in pixels: 1 for the 3x3 first-layer kernels, the padding for the stem kernel */
     /* plan state */
     int built;
     int built_batch, built_w, built_h, built_strict;

@@ -97,7 +97,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // of the following rows come from a carry update (unit grid = pooling windows, row r = 4*window + corner,
     // with the fused pool; pixels without), and the nine tap tests collapse into one product of a column and a
     // row pattern.  The setup runs on the VALU while the matrix pipe waits, so its length matters on short-K layers.
-    const int Wu = a.pool ? a.W >> 1 : a.W, Hu = a.pool ? a.H >> 1 : a.H;
+    // (a.out_h x a.out_w is the output grid the GEMM rows enumerate, a.H x a.W the input the taps are read from:
+    // output (oy, ox) is centred on input (oy*stride, ox*stride) for the pad = size/2 shapes this kernel takes)
+    const int Wu = a.pool ? a.out_w >> 1 : a.out_w, Hu = a.pool ? a.out_h >> 1 : a.out_h;
     const int r0 = p0 + sr;
     const int u0 = a.pool ? r0 >> 2 : r0, tc = r0 & 3;        // RP % 4 == 0: the corner is the same for every q
     int cn = u0 / (Hu * Wu);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
         const int r = r0 + q * RP;                            // GEMM row
-        const int py = a.pool ? 2 * cy + (tc >> 1) : cy, px = a.pool ? 2 * cx + (tc & 1) : cx;
+        const int py = (a.pool ? 2 * cy + (tc >> 1) : cy) * a.stride, px = (a.pool ? 2 * cx + (tc & 1) : cx) * a.stride;
         a_off[q] = ((unsigned)((cn * a.H + py) * a.W + px) * (unsigned)a.ldx + (unsigned)sc * 4u) * 4u;
         unsigned m = 0;
         if (live && r < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
@@ -568,6 +570,103 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
 }
 
 // ---------------------------------------------------------------------------
+// Stem convolutions on a few-channel image: any size / stride with Cin <= 4 (7x7/2 of cfg/yolov1/yolo.cfg,
+// resnet50.cfg, extraction.cfg; 11x11/4 of alexnet.cfg; 3x3 stems the first-layer kernel above does not take).
+// Same shape of kernel as conv_first_kernel -- no im2col, no activation staging: the input carries a zero halo of
+// `pad` pixels ([batch][H+2p][W+2p][ldx]) so no tap needs a bounds test, a wave takes tiles of 32 consecutive output
+// pixels and lane (i, half) loads A[i][k], k = 2t + half, with plain dword loads -- but K = size*size*Cin is too long
+// to keep a filter column in registers, so the packed weights [2t+half][filter] and the per-k input offsets sit in
+// LDS (filled once per workgroup) and one ds_read feeds each MFMA.  K is padded to a multiple of 16 with zero weights.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv_stem_kernel(ConvK a)
+{
+    extern __shared__ __attribute__((aligned(16))) float stem_smem[];
+    constexpr int NC = NT * 32;
+    constexpr int U = 8;                                        // k-pairs per unrolled chunk
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int K = a.size * a.size * a.Cin;
+    const int Tp = ((K + 1) / 2 + U - 1) / U * U;               // k-pairs, padded
+    unsigned *dl = (unsigned *)stem_smem;                       // [2][Tp]: byte offset of tap k = 2t + half from the window origin
+    float *wl = stem_smem + 2 * Tp;                             // [2*Tp][NC]
+    const int W2 = a.W + 2 * a.pad, H2 = a.H + 2 * a.pad;
+    for (int k = threadIdx.x; k < 2 * Tp; k += 256) {
+        const int kk = k < K ? k : K - 1;                       // padding taps re-read the last one (their weights are zero)
+        const int kh = kk / (a.size * a.Cin), rem = kk - kh * a.size * a.Cin;
+        const int kw = rem / a.Cin, ci = rem - kw * a.Cin;
+        dl[(k & 1) * Tp + (k >> 1)] = (unsigned)(((kh * W2 + kw) * a.ldx + ci) * 4);
+    }
+    for (int idx = threadIdx.x; idx < 2 * Tp * NC; idx += 256) {
+        const int k = idx / NC, co = idx - k * NC;
+        wl[idx] = (k < K && co < a.Cout) ? a.w[(size_t)co * K + k] : 0.f;
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    float mean[NT], scale[NT], bias[NT];
+    double rinv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = j * 32 + li;
+        mean[j] = 0.f; scale[j] = 1.f; bias[j] = 0.f; rinv[j] = 1.0;
+        if (co < a.Cout) {
+            bias[j] = a.bias[co];
+            if (a.bn) { mean[j] = a.mean[co]; rinv[j] = a.rinv[co]; scale[j] = a.scale[co]; }
+        }
+    }
+    // contiguous run of tiles per wave: output coordinates advance by a carry update (as in conv_first_kernel)
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long nwaves = (long)gridDim.x * 4;
+    const long ntiles = ((long)a.npix + 31) / 32;
+    const long chunk = (ntiles + nwaves - 1) / nwaves;
+    const long t_begin = wave * chunk, t_end = (t_begin + chunk < ntiles) ? t_begin + chunk : ntiles;
+    long unit = t_begin * 32 + li;
+    int cn, cy, cx;
+    {
+        const long uu = unit < a.npix ? unit : 0;
+        cn = (int)(uu / ((long)a.out_h * a.out_w));
+        const int rem = (int)(uu - (long)cn * a.out_h * a.out_w);
+        cy = rem / a.out_w; cx = rem - cy * a.out_w;
+    }
+    const unsigned *dlh = dl + lh * Tp;
+    const float *wlh = wl + lh * NC + li;
+    for (long tile = t_begin; tile < t_end; ++tile) {
+        const bool live = unit < a.npix;
+        const unsigned base = ((unsigned)(cn * H2 + cy * a.stride) * (unsigned)W2 + (unsigned)(cx * a.stride)) * (unsigned)a.ldx * 4u;
+        unit += 32;
+        cx += 32;
+        while (cx >= a.out_w) { cx -= a.out_w; if (++cy >= a.out_h) { cy = 0; ++cn; } }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int t0 = 0; t0 < Tp; t0 += U) {
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)     // rows past the end read out of range: zeros, no traffic
+                av[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, live ? base + dlh[t0 + u] : a.xbytes, 0, 0));
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], wlh[(size_t)(t0 + u) * 2 * NC + j * 32], acc[j], 0, 0, 0);
+        }
+        const long prow = tile * 32 + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long p = prow + (r & 3) + 8 * (r >> 2);
+                if (co < a.Cout && p < a.npix)
+                    a.y[(size_t)p * a.ldy + co] = epilogue_f32(acc[j][r], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // direct kernel (reference accumulation order; bit-identical to the CPU path)
 // weights in the reference's [n][c][kh][kw] layout
 // ---------------------------------------------------------------------------
@@ -646,9 +745,10 @@ static bool mfma_ok(const y2h_conv *d)
 {
     if (d->x_f16 || d->y_f16) return false;       // the fp32 matrix-core kernel reads and writes fp32 only
     if (!(d->size == 1 || d->size == 3)) return false;
-    if (d->stride != 1 || d->pad != d->size / 2) return false;
+    if (d->stride < 1 || d->pad != d->size / 2) return false;
     if (d->c % 16 != 0 || d->ldx % 4 != 0) return false;
-    if (d->out_h != d->h || d->out_w != d->w) return false;
+    if (d->out_h != (d->h + 2 * d->pad - d->size) / d->stride + 1 || d->out_w != (d->w + 2 * d->pad - d->size) / d->stride + 1) return false;
+    if (d->fuse_maxpool2 && d->stride != 1) return false;
     if (((uintptr_t)d->x | (uintptr_t)d->w_packed) % 16 != 0) return false;
     const double xbytes = (double)d->batch * d->h * d->w * d->ldx * 4.0;
     const double wbytes = (double)d->n * d->size * d->size * d->c * 4.0;
@@ -678,7 +778,7 @@ static int variant_bpc(const Variant &v)               // workgroups co-resident
 static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
 {
     const int bk = (d->c % 32 == 0) ? 32 : 16;
-    const long npix = (long)d->batch * d->h * d->w;
+    const long npix = (long)d->batch * d->out_h * d->out_w;
     const int nk = d->size * d->size * (d->c / bk);
     const int CUS = 256;
     int force_bm = 0, force_bn = 0, force_split = 0;
@@ -735,7 +835,7 @@ extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)
 {
     int ksplit = 1;
     if (d->x_halo || d->x_f16 || !mfma_ok(d) || !pick_variant(d, &ksplit) || ksplit <= 1) return 0;
-    return (size_t)ksplit * d->batch * d->h * d->w * d->n * sizeof(float);
+    return (size_t)ksplit * d->batch * d->out_h * d->out_w * d->n * sizeof(float);
 }
 
 // first-layer kernel: 3 channels, 3x3/1 pad 1, <= 64 filters, input stored with a 1-pixel zero halo
@@ -746,6 +846,33 @@ static bool first_ok(const y2h_conv *d)
     if (d->out_h != d->h || d->out_w != d->w || d->x_halo != 1) return false;
     const double xbytes = (double)d->batch * (d->h + 2) * (d->w + 2) * d->ldx * 4.0;
     return xbytes < 4294967000.0 && d->w_packed != nullptr;
+}
+
+// stem kernel: Cin <= 4, any size / stride, the halo equal to the padding, <= 128 filters, tables within the LDS
+static size_t stem_lds_bytes(const y2h_conv *d)
+{
+    const int K = d->size * d->size * d->c;
+    const int Tp = ((K + 1) / 2 + 7) / 8 * 8;
+    const int NT = (d->n + 31) / 32;
+    return ((size_t)2 * Tp + (size_t)2 * Tp * NT * 32) * sizeof(float);
+}
+
+static bool stem_ok(const y2h_conv *d)
+{
+    if (d->x_f16 || d->y_f16 || d->fuse_maxpool2) return false;
+    if (d->c > 4 || d->n > 128 || d->size < 1 || d->stride < 1 || d->pad < 0 || d->x_halo != d->pad) return false;
+    if (d->out_h != (d->h + 2 * d->pad - d->size) / d->stride + 1 || d->out_w != (d->w + 2 * d->pad - d->size) / d->stride + 1) return false;
+    if (stem_lds_bytes(d) > 160 * 1024) return false;
+    const double xbytes = (double)d->batch * (d->h + 2 * d->pad) * (d->w + 2 * d->pad) * d->ldx * 4.0;
+    return xbytes < 4294967000.0 && d->w_packed != nullptr;
+}
+
+extern "C" int y2h_conv_stem_halo(const y2h_conv *d)
+{
+    y2h_conv t = *d;
+    t.x_halo = t.pad;
+    if (!t.w_packed) t.w_packed = (const float *)(uintptr_t)256;
+    return stem_ok(&t) ? t.pad : -1;
 }
 
 extern "C" int y2h_conv_first_layer_ok(const y2h_conv *d)
@@ -766,7 +893,7 @@ extern "C" int y2h_conv_first_layer_f16_ok(const y2h_conv *d)
 extern "C" int y2h_conv_uses_mfma(const y2h_conv *d)
 {
     if (d->x_f16) return (y2_f16_first_ok(d) || y2_f16_conv_ok(d)) ? 1 : 0;
-    return first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d)) ? 1 : 0;
+    return first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d)) || (d->c <= 4 && stem_ok(d)) ? 1 : 0;
 }
 
 extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
@@ -777,10 +904,11 @@ extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
         const char *nm = strict ? nullptr : y2_f16_conv_variant(d);
         return nm ? nm : "conv_direct_f16";
     }
-    if (!strict && mfma_ok(d)) {
+    if (!strict && d->x_halo == 0 && mfma_ok(d)) {
         Variant *v = pick_variant(d);
         if (v) return v->name;
     }
+    if (!strict && stem_ok(d)) return "conv_stem_mfma_f32";
     return "conv_direct_f32";
 }
 
@@ -822,18 +950,35 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         Y2H_LAUNCH_CHECK();
         return Y2H_OK;
     }
-    if (d->x_halo != 0) return Y2H_EINVAL;       // only the first-layer kernel reads a haloed input
     if (!strict && y2_f16_conv_ok(d)) return y2_f16_conv_launch(d, a, s);
     int ksplit = 1;
-    Variant *v = (!strict && mfma_ok(d)) ? pick_variant(d, &ksplit) : nullptr;
+    Variant *v = (!strict && d->x_halo == 0 && mfma_ok(d)) ? pick_variant(d, &ksplit) : nullptr;
+    if (!v && !strict && stem_ok(d)) {
+        a.w = d->w_packed;
+        a.npix = d->batch * d->out_h * d->out_w;
+        a.xbytes = (unsigned)((size_t)d->batch * (d->h + 2 * d->pad) * (d->w + 2 * d->pad) * d->ldx * 4);
+        const size_t lds = stem_lds_bytes(d);
+        const int nt = (d->n + 31) / 32;
+        void (*fn)(ConvK) = nt == 1 ? conv_stem_kernel<1> : nt == 2 ? conv_stem_kernel<2> : nt == 3 ? conv_stem_kernel<3> : conv_stem_kernel<4>;
+        Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const long ntiles = ((long)a.npix + 31) / 32;
+        int bpc = (int)(160 * 1024 / lds);
+        if (bpc > 4) bpc = 4;
+        long blocks = (ntiles + 3) / 4;
+        if (blocks > 256L * bpc) blocks = 256L * bpc;
+        hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), lds, S(s), a);
+        Y2H_LAUNCH_CHECK();
+        return Y2H_OK;
+    }
+    if (d->x_halo != 0) return Y2H_EINVAL;       // only the first-layer and stem kernels read a haloed input
     if (v) {
         a.ksplit = ksplit;
         if (ksplit > 1) {
-            if (!d->ws || d->ws_bytes < (size_t)ksplit * d->batch * d->h * d->w * d->n * sizeof(float)) return Y2H_EINVAL;
+            if (!d->ws || d->ws_bytes < (size_t)ksplit * d->batch * d->out_h * d->out_w * d->n * sizeof(float)) return Y2H_EINVAL;
             a.ws = d->ws;
         }
         a.w = d->w_packed;
-        a.npix = d->batch * d->h * d->w;
+        a.npix = d->batch * d->out_h * d->out_w;
         a.xbytes = (unsigned)((size_t)d->batch * d->h * d->w * d->ldx * 4);
         a.wbytes = (unsigned)((size_t)d->n * a.K * 4);
         a.tiles_n = (d->n + v->bn - 1) / v->bn;

@@ -22,7 +22,7 @@ struct ConvK {
     int vec_store;     // fp16 kernels: half outputs leave as 16-byte stores (ldy, y and Cout aligned to 8 halves)
     int dbg;           // ablation switches for tuning runs (env Y2_DBG; 0 in normal use): see y2_conv_f16.hip
     int H, W, Cin, ldx, Cout, ldy, K;
-    int npix;          // batch * H * W (output pixels == input pixels for the MFMA path)
+    int npix;          // GEMM rows = output pixels: batch * out_h * out_w (== batch * H * W at stride 1)
     int pool;          // 1: a 2x2 stride-2 maxpool is fused behind the activation (see pool_pixel)
     int bn, act;
     unsigned xbytes, wbytes;
@@ -30,7 +30,7 @@ struct ConvK {
     int ntiles;        // tiles_m * tiles_n * ksplit work items; workgroups walk them with stride gridDim.x
     int ksplit;        // >= 1: number of K ranges each output tile is cut into (split-K)
     float *ws;         // split-K partial sums [ksplit][npix][Cout]
-    // direct kernel only
+    // stride / out_h / out_w: fp32 matrix-core and direct kernels; size / pad / batch: direct kernel only
     int size, stride, pad, out_h, out_w, batch;
 };
 

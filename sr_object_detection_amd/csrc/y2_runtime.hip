@@ -162,10 +162,10 @@ extern "C" int y2h_nhwc_to_nchw(const float *src, int ld, float *dst, int n, int
     return Y2H_OK;
 }
 
-// few-channel NCHW -> NHWC with a one-pixel halo: one thread per pixel reads its c planes
+// few-channel NCHW -> NHWC with a `halo`-pixel border: one thread per pixel reads its c planes
 // (coalesced along x) and writes c contiguous floats into the interior of the padded image
 __global__ __launch_bounds__(256) void nchw_to_nhwc_halo_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                                int c, int h, int w, int ld, long total)
+                                                                int c, int h, int w, int ld, int halo, long total)
 {
     const long hw = (long)h * w;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -173,16 +173,16 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_halo_kernel(const float *__r
         const int y = (int)((idx / w) % h);
         const long n = idx / hw;
         const float *s = src + n * c * hw + (long)y * w + x;
-        float *d = dst + ((n * (h + 2) + (y + 1)) * (long)(w + 2) + (x + 1)) * ld;
+        float *d = dst + ((n * (h + 2 * halo) + (y + halo)) * (long)(w + 2 * halo) + (x + halo)) * ld;
         for (int k = 0; k < c; ++k) d[k] = s[k * hw];
     }
 }
 
-extern "C" int y2h_nchw_to_nhwc_halo(const float *src, float *dst, int n, int c, int h, int w, int ld, y2h_stream s)
+extern "C" int y2h_nchw_to_nhwc_halo(const float *src, float *dst, int n, int c, int h, int w, int ld, int halo, y2h_stream s)
 {
-    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || ld < c) return Y2H_EINVAL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || ld < c || halo < 0) return Y2H_EINVAL;
     const long total = (long)n * h * w;
-    hipLaunchKernelGGL(nchw_to_nhwc_halo_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), src, dst, c, h, w, ld, total);
+    hipLaunchKernelGGL(nchw_to_nhwc_halo_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), src, dst, c, h, w, ld, halo, total);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }

@@ -15,7 +15,7 @@ synthetic weights and to report FLOPs; the engine does its own parse in C.
 from __future__ import annotations
 
 # spec entries:
-#   ("conv", filters, size, bn, activation)      stride 1, pad=1
+#   ("conv", filters, size, bn, activation[, stride[, pad flag]])      default stride 1, pad=1 (= size/2 pixels)
 #   ("max", size, stride) | ("route", [idx...]) | ("reorg", stride)
 #   ("region", dict) | ("avg",) | ("softmax",) | ("cost",)
 #   ("crop", width, height, noadjust) | ("batchnorm",) | ("local", filters, size, stride, pad, activation)
@@ -141,7 +141,7 @@ def cfg_text(name: str, width: int | None = None, height: int | None = None, bat
         if kind == "conv":
             _, filters, size, bn, act = e[:5]
             stride = e[5] if len(e) > 5 else 1
-            out += ["[convolutional]", "filters=%d" % filters, "size=%d" % size, "stride=%d" % stride, "pad=1"]
+            out += ["[convolutional]", "filters=%d" % filters, "size=%d" % size, "stride=%d" % stride, "pad=%d" % (e[6] if len(e) > 6 else 1)]
             if bn:
                 out.append("batch_normalize=1")
             out += ["activation=%s" % act, ""]
@@ -203,7 +203,7 @@ def resolve(name_or_spec, width: int, height: int | None = None, channels: int =
         if kind == "conv":
             _, filters, size, bn, act = e[:5]
             stride = e[5] if len(e) > 5 else 1
-            pad = size // 2
+            pad = size // 2 if (e[6] if len(e) > 6 else 1) else 0
             L.update(type="convolutional", filters=filters, size=size, stride=stride, pad=pad, batch_normalize=bn,
                      activation=act, out_w=(w + 2 * pad - size) // stride + 1, out_h=(h + 2 * pad - size) // stride + 1,
                      out_c=filters)

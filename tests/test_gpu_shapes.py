@@ -81,3 +81,64 @@ def test_set_batch_to_one_on_a_batched_cfg(oracle, workdir):
         one = net.network_predict(x[b:b + 1])
         assert np.abs(one - full[b]).max() < 5e-5      # (a different batch may pick another tile / K-split)
     net.free()
+
+
+@pytest.mark.parametrize("w,h,batch", [(64, 64, 2), (52, 36, 3), (33, 47, 1)])
+def test_strided_convolutions_on_the_matrix_cores(oracle, workdir, w, h, batch):
+    """3x3 and 1x1 convolutions with stride 2 and 3 (cfg/yolov1/yolo.cfg, resnet50.cfg, strided.cfg) take the implicit-GEMM
+    kernel: the GEMM rows enumerate the output grid, the taps are centred on input (oy*stride, ox*stride).  Even and odd
+    input sizes (the last tap column / row falls outside for odd ones), every layer against the oracle."""
+    spec = [("conv", 16, 3, 1, "leaky"), ("conv", 32, 3, 1, "leaky", 2), ("conv", 32, 1, 1, "leaky", 2), ("conv", 48, 3, 1, "leaky"),
+            ("conv", 64, 3, 1, "leaky", 3), ("conv", 30, 1, 0, "linear"),
+            ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]})]
+    cfg = os.path.join(workdir, "strided_%dx%d_b%d.cfg" % (w, h, batch))
+    open(cfg, "w").write(zoo.cfg_text("strided", w, h, batch, spec=spec))
+    wts = os.path.join(workdir, "strided_%dx%d.weights" % (w, h))
+    synth.write_weights(wts, zoo.resolve(spec, w, h), 99, 4.0)
+    x = synth.image_batch(batch, 3, h, w, seed=100)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    out = net.network_predict(x)
+    assert [net.layer_kernel(i).startswith("conv_mfma_f32") for i in (1, 2, 4)] == [True, True, True], [net.layer_kernel(i) for i in range(net.n)]
+    for i in range(net.n):
+        got, want = net.pull_layer_output(i), on.layer_output(i)
+        assert got.shape == want.shape and np.abs(got - want).max() < TOL * max(1.0, float(np.abs(want).max())), (i, net.layer_kernel(i))
+    assert np.abs(out - ref).max() < TOL
+    net.set_strict(True)
+    assert np.array_equal(net.network_predict(x), ref)
+    net.free()
+    on.close()
+
+
+@pytest.mark.parametrize("stem,w,h,batch", [(("conv", 64, 7, 1, "leaky", 2), 64, 48, 2),      # yolov1 / resnet50 / extraction stem
+                                            (("conv", 40, 11, 0, "relu", 4, 0), 67, 59, 1),   # alexnet: no padding, bias only
+                                            (("conv", 96, 5, 1, "leaky", 1), 33, 21, 3),      # three filter tiles, odd sizes
+                                            (("conv", 20, 3, 1, "leaky", 2), 40, 40, 2)])     # 3x3/2 stem (tiny.cfg-like)
+def test_few_channel_stem_convolutions(oracle, workdir, stem, w, h, batch):
+    """first layers other than 3x3/1 run on the stem kernel (haloed input, weights in LDS) and match the oracle"""
+    spec = [stem, ("conv", 32, 3, 1, "leaky"), ("conv", 30, 1, 0, "linear"),
+            ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]})]
+    tag = "stem_%d_%d_%dx%d" % (stem[2], stem[5], w, h)
+    cfg = os.path.join(workdir, tag + ".cfg")
+    open(cfg, "w").write(zoo.cfg_text(tag, w, h, batch, spec=spec))
+    wts = os.path.join(workdir, tag + ".weights")
+    synth.write_weights(wts, zoo.resolve(spec, w, h), 17, 4.0)
+    x = synth.image_batch(batch, 3, h, w, seed=18)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    out = net.network_predict(x)
+    assert net.layer_kernel(0) == "conv_stem_mfma_f32", net.layer_kernel(0)
+    for i in range(net.n):
+        got, want = net.pull_layer_output(i), on.layer_output(i)
+        assert got.shape == want.shape and np.abs(got - want).max() < TOL * max(1.0, float(np.abs(want).max())), (i, net.layer_kernel(i))
+    assert np.abs(out - ref).max() < TOL
+    net.set_strict(True)
+    assert np.array_equal(net.network_predict(x), ref)
+    net.set_strict(False)
+    assert np.abs(net.network_predict(x) - ref).max() < TOL      # re-planned back onto the stem kernel
+    net.free()
+    on.close()
