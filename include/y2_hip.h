@@ -47,8 +47,13 @@ extern "C" {
 typedef void *y2h_stream;   /* hipStream_t */
 typedef void *y2h_event;    /* hipEvent_t */
 
-/* activation codes (subset of src_yolo2/activations.h:7 used by the target cfgs) */
-enum { Y2H_ACT_LINEAR = 0, Y2H_ACT_LEAKY = 1, Y2H_ACT_LOGISTIC = 2, Y2H_ACT_RELU = 3 };
+/* activation codes (src_yolo2/activations.h:7).  0-3 are the ones the target cfgs use and every kernel's epilogue
+ * applies in place; the others only exist as the separate pass y2h_activate_array (the engine then runs the
+ * producing kernel with Y2H_ACT_LINEAR, which is exactly the reference's own order: activate_array is a pass of its
+ * own over the stored fp32 output, activations.c:95-101) */
+enum { Y2H_ACT_LINEAR = 0, Y2H_ACT_LEAKY = 1, Y2H_ACT_LOGISTIC = 2, Y2H_ACT_RELU = 3,
+       Y2H_ACT_RELIE = 4, Y2H_ACT_RAMP = 5, Y2H_ACT_TANH = 6, Y2H_ACT_PLSE = 7, Y2H_ACT_ELU = 8, Y2H_ACT_LOGGY = 9,
+       Y2H_ACT_STAIR = 10, Y2H_ACT_HARDTAN = 11, Y2H_ACT_LHTAN = 12 };
 
 /* ---- device / memory / streams (cuda.h:24-33) ---- */
 int         y2h_device_count(void);
@@ -161,9 +166,10 @@ int y2h_detection_boxes(const float *pred, long pred_stride, int batch, int side
  * w1 x h1 x c1, in/out are w2 x h2 x c2; stride = w1/w2 and sample = w2/w1 (each >= 1) as in shortcut_cpu */
 int y2h_shortcut(const float *in, int ld_in, const float *add, int ld_add, float *out, int ld_out, int batch,
                  int w1, int h1, int c1, int w2, int h2, int c2, int activation, y2h_stream s);
-/* [crop] at inference (crop_layer.c:69-105, !state.train): centred out_h x out_w window, x*2-1 unless noadjust */
+/* [crop] at inference (crop_layer.c:69-105, !state.train): centred out_h x out_w window, x*2-1 unless noadjust.
+ * halo > 0: y is [batch][out_h+2*halo][out_w+2*halo][ldy] and only its interior is written (the caller zeroes it once) */
 int y2h_crop(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c, int out_h, int out_w,
-             int noadjust, y2h_stream s);
+             int noadjust, int halo, y2h_stream s);
 /* standalone [batchnorm] at inference (batchnorm_layer.c:122-146): ((x - mean) * rinv) * scale per channel, rinv =
  * 1 / (sqrt(var) + 1e-6f) prepared in double (blas.c:122) */
 int y2h_batchnorm(const float *x, int ldx, float *y, int ldy, long pixels, int c, const float *mean, const double *rinv,
@@ -174,6 +180,9 @@ int y2h_batchnorm(const float *x, int ldx, float *y, int ldy, long pixels, int c
 int y2h_local(const float *x, int ldx, const float *w_packed, const float *bias_packed, float *y, int ldy, int batch,
               int h, int w, int c, int n, int size, int stride, int pad, int out_h, int out_w, int activation,
               int strict, y2h_stream s);
+/* activate_array (activations.c:95-101, the formulas of activations.h:21-54) in place on channels 0..c-1 of `rows`
+ * pixels with channel stride ld; any Y2H_ACT_* code */
+int y2h_activate_array(float *x, int ld, long rows, int c, int activation, y2h_stream s);
 /* global average pool: [batch][h*w][ld] -> [batch][c] (sequential fp32 sum, avgpool_layer.c:40) */
 int y2h_avgpool(const float *x, int ldx, float *y, int batch, int h, int w, int c, y2h_stream s);
 /* rows of `n` floats: softmax with temperature (blas.c:205); in/out may alias */

@@ -30,7 +30,8 @@
 
 enum { ORC_CONV = 0, ORC_MAXPOOL, ORC_ROUTE, ORC_REORG, ORC_REGION, ORC_AVGPOOL, ORC_SOFTMAX, ORC_COST, ORC_SHORTCUT,
        ORC_CONNECTED, ORC_DROPOUT, ORC_DETECTION, ORC_CROP, ORC_LOCAL, ORC_BATCHNORM };
-enum { ACT_LOGISTIC = 0, ACT_RELU, ACT_LINEAR, ACT_LEAKY, ACT_RAMP, ACT_TANH, ACT_ELU, ACT_HARDTAN };
+enum { ACT_LOGISTIC = 0, ACT_RELU, ACT_LINEAR, ACT_LEAKY, ACT_RAMP, ACT_TANH, ACT_ELU, ACT_HARDTAN,
+       ACT_RELIE, ACT_PLSE, ACT_LOGGY, ACT_STAIR, ACT_LHTAN };
 
 typedef struct {
     int n;            /* nodes */
@@ -173,6 +174,11 @@ static int activation_from_name(const char *s)   /* activations.c get_activation
     if (!strcmp(s, "tanh")) return ACT_TANH;
     if (!strcmp(s, "elu")) return ACT_ELU;
     if (!strcmp(s, "hardtan")) return ACT_HARDTAN;
+    if (!strcmp(s, "relie")) return ACT_RELIE;
+    if (!strcmp(s, "plse")) return ACT_PLSE;
+    if (!strcmp(s, "loggy")) return ACT_LOGGY;
+    if (!strcmp(s, "stair")) return ACT_STAIR;
+    if (!strcmp(s, "lhtan")) return ACT_LHTAN;
     fprintf(stderr, "Couldn't find activation function %s, going with ReLU\n", s);
     return ACT_RELU;
 }
@@ -639,6 +645,11 @@ static float act(float x, int a)   /* activations.h:30-47, activations.c:62-94 *
     case ACT_TANH: return (exp(2 * x) - 1) / (exp(2 * x) + 1);
     case ACT_ELU: return (x >= 0) * x + (x < 0) * (exp(x) - 1);
     case ACT_HARDTAN: return x < -1 ? -1 : (x > 1 ? 1 : x);
+    case ACT_RELIE: return (x > 0) ? x : .01 * x;
+    case ACT_PLSE: if (x < -4) return .01 * (x + 4); if (x > 4) return .01 * (x - 4) + 1; return .125 * x + .5;
+    case ACT_LOGGY: return 2. / (1. + exp(-x)) - 1;
+    case ACT_STAIR: { int n = floor(x); if (n % 2 == 0) return floor(x / 2.); return (x - n) + floor(x / 2.); }
+    case ACT_LHTAN: if (x < 0) return .001 * x; if (x > 1) return .001 * (x - 1) + 1; return x;
     }
     return 0;
 }

@@ -93,6 +93,7 @@ static void free_plan(network *net)
         y2h_free(d->out_alloc); d->out_alloc = NULL; d->out = NULL;
         y2h_free(d->d_region); d->d_region = NULL;
         y2h_free(d->d_flat); d->d_flat = NULL;
+        y2h_free(d->d_halo); d->d_halo = NULL; d->halo_px = 0;
         d->placed_in = -1; d->alias_of = -1; d->copy_mask = 0;
         d->fused_pool = 0; d->fused_into = -1;
         d->out_half = 0;
@@ -157,6 +158,31 @@ static int producer_can_place(const layer *l)
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+/* device code of a reference ACTIVATION (activations.h:7) */
+static int act_code(ACTIVATION a)
+{
+    switch (a) {
+    case LINEAR: return Y2H_ACT_LINEAR;
+    case LEAKY: return Y2H_ACT_LEAKY;
+    case LOGISTIC: return Y2H_ACT_LOGISTIC;
+    case RELU: return Y2H_ACT_RELU;
+    case RELIE: return Y2H_ACT_RELIE;
+    case RAMP: return Y2H_ACT_RAMP;
+    case TANH: return Y2H_ACT_TANH;
+    case PLSE: return Y2H_ACT_PLSE;
+    case ELU: return Y2H_ACT_ELU;
+    case LOGGY: return Y2H_ACT_LOGGY;
+    case STAIR: return Y2H_ACT_STAIR;
+    case HARDTAN: return Y2H_ACT_HARDTAN;
+    case LHTAN: return Y2H_ACT_LHTAN;
+    }
+    return -1;
+}
+/* the four activations of the target cfgs are applied in the producing kernel's epilogue; the others run as the
+ * reference runs every activation -- a pass of their own over the stored output (activations.c:95) */
+static int act_in_kernel(ACTIVATION a) { const int c = act_code(a); return c >= 0 && c <= Y2H_ACT_RELU; }
+static int act_for_kernel(ACTIVATION a) { return act_in_kernel(a) ? act_code(a) : Y2H_ACT_LINEAR; }
+
 static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, int ldx)
 {
     const layer *l = &net->layers[i];
@@ -167,15 +193,10 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     c->n = l->n; c->size = l->size; c->stride = l->stride; c->pad = l->pad;
     c->out_h = l->out_h; c->out_w = l->out_w; c->ldy = d->out_ld;
     c->batch_normalize = l->batch_normalize;
-    switch (l->activation) {
-    case LINEAR: c->activation = Y2H_ACT_LINEAR; break;
-    case LEAKY: c->activation = Y2H_ACT_LEAKY; break;
-    case LOGISTIC: c->activation = Y2H_ACT_LOGISTIC; break;
-    case RELU: c->activation = Y2H_ACT_RELU; break;
-    default: c->activation = -1; break;
-    }
+    c->activation = act_for_kernel(l->activation);
     c->x = x;
     c->x_halo = (i == 0 && e->in_halo) ? e->in_halo_px : 0;   /* in_halo 2: half [b][h+2][w+2][4] for the fp16 first-layer kernel */
+    if (i > 0 && ld_of(&net->layers[i - 1])->d_halo) c->x_halo = ld_of(&net->layers[i - 1])->halo_px;
     c->fuse_maxpool2 = d->fused_pool;
     c->ws = e->d_ws;
     c->ws_bytes = e->ws_bytes;
@@ -202,7 +223,11 @@ static void input_view(const network *net, int i, const float **x, int *ldx)
 {
     const y2_engine *e = y2_engine_of(net);
     if (i == 0) { *x = e->d_in_nhwc; *ldx = (e->in_halo == 2) ? 4 : net->c; }
-    else { const y2_ldev *p = ld_of(&net->layers[i - 1]); *x = p->out; *ldx = p->out_ld; }
+    else {
+        const y2_ldev *p = ld_of(&net->layers[i - 1]);
+        *x = p->out; *ldx = p->out_ld;
+        if (p->d_halo && net->layers[i].type == CONVOLUTIONAL) { *x = p->d_halo; *ldx = net->layers[i - 1].out_c; }
+    }
     /* a [connected] layer is run as a 1x1 convolution over a 1x1 image whose channels are the whole input vector */
     if (net->layers[i].type == CONNECTED) *ldx = net->layers[i].inputs;
 }
@@ -403,6 +428,7 @@ int y2_engine_build(network *net)
             if (l->type != CONVOLUTIONAL || m->type != MAXPOOL) continue;
             if (m->size != 2 || m->stride != 2 || m->pad != 0 || (l->out_h & 1) || (l->out_w & 1)) continue;
             if (l->stride != 1 || l->pad != l->size / 2 || !(l->size == 1 || l->size == 3)) continue;
+            if (!act_in_kernel(l->activation)) continue;       /* the separate activation pass must see every pixel */
             if (!((l->c % 16 == 0) || (i == 0 && l->c == 3 && l->size == 3 && l->n <= 64))) continue;
             if (i == e->out_layer || ld_of(l)->placed_in >= 0) continue;
             for (j = 0; j < net->n; ++j) {
@@ -422,6 +448,7 @@ int y2_engine_build(network *net)
             y2_ldev *d = ld_of(l), *pd = i > 0 ? ld_of(&net->layers[i - 1]) : NULL;
             switch (l->type) {
             case CONVOLUTIONAL:
+                if (!act_in_kernel(l->activation)) { y2_fail("fp16 mode: layer %d: activation %d has no half-precision form", i, (int)l->activation); return -1; }
                 /* the conv feeding a region head writes fp32: the head's logistic/softmax/exp run in fp32 */
                 d->out_half = !(i + 1 < net->n && net->layers[i + 1].type == REGION);
                 break;
@@ -540,6 +567,29 @@ int y2_engine_build(network *net)
             ld_of(&net->layers[i + 1])->kernel = "(fused into the conv before)";
         }
     }
+    /* a [crop] in front of a few-channel convolution (vgg-16.cfg, strided.cfg, yolov1/yolo-small.cfg) also writes its
+     * window with the zero border the first-layer / stem kernels want */
+    if (!e->strict && !e->half) {
+        for (i = 0; i + 1 < net->n; ++i) {
+            const layer *l = &net->layers[i], *nl = &net->layers[i + 1];
+            y2_ldev *d = ld_of(l);
+            y2h_conv c0;
+            int px;
+            if (l->type != CROP || nl->type != CONVOLUTIONAL || nl->c > 4 || ld_of(nl)->fused_pool) continue;
+            memset(&c0, 0, sizeof c0);
+            c0.batch = nl->batch; c0.h = nl->h; c0.w = nl->w; c0.c = nl->c; c0.ldx = nl->c; c0.n = nl->n;
+            c0.size = nl->size; c0.stride = nl->stride; c0.pad = nl->pad; c0.out_h = nl->out_h; c0.out_w = nl->out_w;
+            c0.w_packed = (const float *)(uintptr_t)256;
+            px = y2h_conv_first_layer_ok(&c0) ? 1 : y2h_conv_stem_halo(&c0);
+            if (px <= 0) continue;
+            {
+                const size_t fl = (size_t)l->batch * (l->out_h + 2 * px) * (l->out_w + 2 * px) * l->out_c;
+                HIPCALL(y2h_malloc((void **)&d->d_halo, fl * sizeof(float)));
+                HIPCALL(y2h_memset(d->d_halo, 0, fl * sizeof(float), e->stream));
+                d->halo_px = px;
+            }
+        }
+    }
     /* io */
     e->in_floats = (size_t)net->batch * net->inputs;
     e->in_halo = 0;
@@ -652,19 +702,12 @@ int y2_engine_build(network *net)
             continue;
         }
         if (l->type == LOCAL) {
-            if (l->activation != LINEAR && l->activation != LEAKY && l->activation != LOGISTIC && l->activation != RELU) {
-                y2_fail("layer %d: activation %d is not implemented on the device", i, (int)l->activation);
-                return -1;
-            }
             d->off_w_packed = off; off = align_up(off + (size_t)l->out_h * l->out_w * l->n * l->size * l->size * l->c * sizeof(float), 256);
             d->off_bias = off; off = align_up(off + (size_t)l->outputs * sizeof(float), 64);
             continue;
         }
         if (l->type != CONVOLUTIONAL && l->type != CONNECTED) continue;
-        if (l->activation != LINEAR && l->activation != LEAKY && l->activation != LOGISTIC && l->activation != RELU) {
-            y2_fail("layer %d: activation %d is not implemented on the device", i, (int)l->activation);
-            return -1;
-        }
+        if (act_code(l->activation) < 0) { y2_fail("layer %d: unknown activation %d", i, (int)l->activation); return -1; }
         wbytes = (size_t)l->n * l->size * l->size * l->c * sizeof(float);
         w_half = (i > 0) && ld_of(&net->layers[i - 1])->out_half;
         input_view(net, i, &x, &ldx);
@@ -778,6 +821,8 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
             y2h_conv c;
             conv_desc(net, i, &c, x, ldx);
             HIPCALL(y2h_conv_forward(&c, e->strict, e->stream));
+            if (!act_in_kernel(l->activation))
+                HIPCALL(y2h_activate_array(d->out, d->out_ld, (long)l->batch * l->out_h * l->out_w, l->out_c, act_code(l->activation), e->stream));
         } break;
         case MAXPOOL:
             if (d->fused_into >= 0) break;       /* already produced by the conv before it */
@@ -846,6 +891,8 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
                 HIPCALL(y2h_connected_ref(x, (long)l->inputs, flat ? cc : ld_of(pl)->out_ld, hw, cc, c.w_ref, d->d_flat, l->outputs,
                                           l->batch, l->batch_normalize, c.activation, c.mean, c.rinv, c.scale, c.bias, e->stream));
             }
+            if (!act_in_kernel(l->activation))
+                HIPCALL(y2h_activate_array(d->d_flat, l->outputs, (long)l->batch, l->outputs, act_code(l->activation), e->stream));
         } break;
         case DROPOUT:
             break;                    /* dropout_layer.c:34: nothing happens at inference; the output is the input */
@@ -860,26 +907,29 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
         } break;
         case SHORTCUT: {
             const y2_ldev *fd = ld_of(&net->layers[l->index]);
-            int act = l->activation == LEAKY ? Y2H_ACT_LEAKY : l->activation == LOGISTIC ? Y2H_ACT_LOGISTIC :
-                      l->activation == RELU ? Y2H_ACT_RELU : l->activation == LINEAR ? Y2H_ACT_LINEAR : -1;
-            if (act < 0) { y2_fail("shortcut layer %d: activation %d is not implemented on the device", i, (int)l->activation); return -1; }
+            if (act_code(l->activation) < 0) { y2_fail("shortcut layer %d: unknown activation %d", i, (int)l->activation); return -1; }
             if (i == 0) { y2_fail("shortcut layer %d has no input layer", i); return -1; }
             HIPCALL(y2h_shortcut(x, ldx, fd->out, fd->out_ld, d->out, d->out_ld, l->batch, l->w, l->h, l->c,
-                                 l->out_w, l->out_h, l->out_c, act, e->stream));
+                                 l->out_w, l->out_h, l->out_c, act_for_kernel(l->activation), e->stream));
+            if (!act_in_kernel(l->activation))
+                HIPCALL(y2h_activate_array(d->out, d->out_ld, (long)l->batch * l->out_h * l->out_w, l->out_c, act_code(l->activation), e->stream));
         } break;
         case CROP:
-            HIPCALL(y2h_crop(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->out_h, l->out_w, l->noadjust, e->stream));
+            HIPCALL(y2h_crop(x, ldx, d->out, d->out_ld, l->batch, l->h, l->w, l->c, l->out_h, l->out_w, l->noadjust, 0, e->stream));
+            if (d->d_halo)
+                HIPCALL(y2h_crop(x, ldx, d->d_halo, l->out_c, l->batch, l->h, l->w, l->c, l->out_h, l->out_w, l->noadjust, d->halo_px, e->stream));
             break;
         case BATCHNORM:
             HIPCALL(y2h_batchnorm(x, ldx, d->out, d->out_ld, (long)l->batch * l->h * l->w, l->c, (const float *)(e->arena + d->off_mean),
                                   (const double *)(e->arena + d->off_rinv), (const float *)(e->arena + d->off_scale), e->stream));
             break;
         case LOCAL: {
-            int act = l->activation == LEAKY ? Y2H_ACT_LEAKY : l->activation == LOGISTIC ? Y2H_ACT_LOGISTIC :
-                      l->activation == RELU ? Y2H_ACT_RELU : Y2H_ACT_LINEAR;
+            if (act_code(l->activation) < 0) { y2_fail("local layer %d: unknown activation %d", i, (int)l->activation); return -1; }
             HIPCALL(y2h_local(x, ldx, (const float *)(e->arena + d->off_w_packed), (const float *)(e->arena + d->off_bias), d->out,
-                              d->out_ld, l->batch, l->h, l->w, l->c, l->n, l->size, l->stride, l->pad, l->out_h, l->out_w, act,
-                              e->strict, e->stream));
+                              d->out_ld, l->batch, l->h, l->w, l->c, l->n, l->size, l->stride, l->pad, l->out_h, l->out_w,
+                              act_for_kernel(l->activation), e->strict, e->stream));
+            if (!act_in_kernel(l->activation))
+                HIPCALL(y2h_activate_array(d->out, d->out_ld, (long)l->batch * l->out_h * l->out_w, l->out_c, act_code(l->activation), e->stream));
         } break;
         case COST:
             break;                    /* cost_layer.c:75: nothing happens without truth */

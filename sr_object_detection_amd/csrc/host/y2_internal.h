@@ -36,6 +36,10 @@ typedef struct y2_ldev {
     float *d_region;           /* [batch][outputs] flattened region output */
     /* classifier tail */
     float *d_flat;             /* avgpool / softmax output [batch][outputs] */
+    /* [crop] in front of a few-channel convolution: a second copy of the window with a zero border of halo_px
+     * pixels ([batch][out_h+2p][out_w+2p][out_c]), which is what the first-layer / stem kernels read */
+    float *d_halo;
+    int halo_px;
     const char *kernel;        /* name for profiles */
 } y2_ldev;
 

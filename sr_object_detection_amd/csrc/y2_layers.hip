@@ -390,7 +390,7 @@ extern "C" int y2h_shortcut(const float *in, int ld_in, const float *add, int ld
 // each value mapped x*scale + trans (2, -1 unless noadjust).  NHWC in, NHWC out; one thread per value.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void crop_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy, int h, int w,
-                                                   int c, int oh, int ow, int dh, int dw, float scale, float trans, long total)
+                                                   int c, int oh, int ow, int dh, int dw, int halo, float scale, float trans, long total)
 {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int k = (int)(idx % c);
@@ -399,18 +399,18 @@ __global__ __launch_bounds__(256) void crop_kernel(const float *__restrict__ x, 
         const int oy = (int)((pix / ow) % oh);
         const long b = pix / ((long)ow * oh);
         const float v = x[((b * h + oy + dh) * w + ox + dw) * ldx + k];
-        y[pix * ldy + k] = v * scale + trans;
+        y[((b * (oh + 2 * halo) + oy + halo) * (long)(ow + 2 * halo) + ox + halo) * ldy + k] = v * scale + trans;
     }
 }
 
 extern "C" int y2h_crop(const float *x, int ldx, float *y, int ldy, int batch, int h, int w, int c, int out_h, int out_w,
-                        int noadjust, y2h_stream s)
+                        int noadjust, int halo, y2h_stream s)
 {
-    if (!x || !y || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || out_h <= 0 || out_w <= 0 || out_h > h || out_w > w) return Y2H_EINVAL;
+    if (!x || !y || batch <= 0 || h <= 0 || w <= 0 || c <= 0 || out_h <= 0 || out_w <= 0 || out_h > h || out_w > w || halo < 0) return Y2H_EINVAL;
     if (ldx < c || ldy < c) return Y2H_EINVAL;
     const long total = (long)batch * out_h * out_w * c;
     hipLaunchKernelGGL(crop_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), x, ldx, y, ldy, h, w, c, out_h, out_w,
-                       (h - out_h) / 2, (w - out_w) / 2, noadjust ? 1.f : 2.f, noadjust ? 0.f : -1.f, total);
+                       (h - out_h) / 2, (w - out_w) / 2, halo, noadjust ? 1.f : 2.f, noadjust ? 0.f : -1.f, total);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }
@@ -458,6 +458,57 @@ __device__ __forceinline__ float activate_ref(float v, int act)
     else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));
     else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);
     return v;
+}
+
+// every activation of activations.h:21-54, with the reference's own promotion rules (float x, double constants, the
+// result rounded to float on return)
+__device__ float activate_any(float x, int act)
+{
+    const double xd = (double)x;
+    switch (act) {
+    case Y2H_ACT_LINEAR: return x;
+    case Y2H_ACT_LEAKY: return (x > 0) ? x : (float)(.1 * xd);
+    case Y2H_ACT_LOGISTIC: return (float)(1. / (1. + exp(-xd)));
+    case Y2H_ACT_RELU: return x * (float)(x > 0);
+    case Y2H_ACT_RELIE: return (x > 0) ? x : (float)(.01 * xd);
+    case Y2H_ACT_RAMP: return (float)((double)(x * (float)(x > 0)) + .1 * xd);
+    case Y2H_ACT_TANH: { const float t = 2 * x; return (float)((exp((double)t) - 1) / (exp((double)t) + 1)); }
+    case Y2H_ACT_PLSE:
+        if (x < -4) return (float)(.01 * (double)(x + 4));
+        if (x > 4) return (float)(.01 * (double)(x - 4) + 1);
+        return (float)(.125 * xd + .5);
+    case Y2H_ACT_ELU: return (float)((double)((float)(x >= 0) * x) + (double)(x < 0) * (exp(xd) - 1));
+    case Y2H_ACT_LOGGY: return (float)(2. / (1. + exp(-xd)) - 1);
+    case Y2H_ACT_STAIR: {
+        const int n = (int)floor(xd);
+        if (n % 2 == 0) return (float)floor(xd / 2.);
+        return (float)((double)(x - (float)n) + floor(xd / 2.));
+    }
+    case Y2H_ACT_HARDTAN: return x < -1 ? -1.f : (x > 1 ? 1.f : x);
+    case Y2H_ACT_LHTAN:
+        if (x < 0) return (float)(.001 * xd);
+        if (x > 1) return (float)(.001 * (double)(x - 1) + 1);
+        return x;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void activate_kernel(float *__restrict__ x, int ld, int c, int act, long total)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / c;
+        const int k = (int)(idx - row * c);
+        x[row * ld + k] = activate_any(x[row * ld + k], act);
+    }
+}
+
+extern "C" int y2h_activate_array(float *x, int ld, long rows, int c, int activation, y2h_stream s)
+{
+    if (!x || rows <= 0 || c <= 0 || ld < c || activation < 0 || activation > Y2H_ACT_LHTAN) return Y2H_EINVAL;
+    const long total = rows * c;
+    hipLaunchKernelGGL(activate_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), x, ld, c, activation, total);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
 }
 
 struct LocalK {

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 # spec entries:
 #   ("conv", filters, size, bn, activation[, stride[, pad flag]])      default stride 1, pad=1 (= size/2 pixels)
-#   ("max", size, stride) | ("route", [idx...]) | ("reorg", stride)
+#   ("max", size, stride[, padding]) | ("route", [idx...]) | ("reorg", stride)
 #   ("region", dict) | ("avg",) | ("softmax",) | ("cost",)
 #   ("crop", width, height, noadjust) | ("batchnorm",) | ("local", filters, size, stride, pad, activation)
 
@@ -112,6 +112,83 @@ SPECS["mini-v1-local"] = [
     ("detection", {"classes": 5, "num": 2, "side": 4, "softmax": 1, "sqrt": 1}),
 ]
 
+# ---- the reference's other cfg files (classifiers and the YOLOv1 family), restated from their structure.  tests/
+# test_capi_host.py checks, where /root/reference exists, that each text parses to the same layer table as the file.
+_CLS_HEAD = [("avg",), ("softmax",), ("cost",)]
+
+
+def _resnet50():                      # cfg/resnet50.cfg: 7x7/2 stem, 3-4-6-3 bottleneck blocks joined by [shortcut]
+    s = [("conv", 64, 7, 1, "leaky", 2), ("max", 2, 2)]
+    for width, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for b in range(blocks):
+            s += [("conv", width, 1, 1, "leaky"), ("conv", width, 3, 1, "leaky", stride if b == 0 else 1),
+                  ("conv", 4 * width, 1, 1, "linear"), ("shortcut", -4, "leaky")]
+    return s + [("conv", 1000, 1, 0, "linear")] + _CLS_HEAD
+
+
+def _densenet201():                   # cfg/densenet201.cfg: dense blocks of 6-12-48-32 (1x1 128, 3x3 32, route -1,-3)
+    s = [("conv", 64, 7, 1, "leaky", 2), ("max", 2, 2)]
+    for blocks, trans in ((6, 128), (12, 256), (48, 512), (32, None)):
+        for _ in range(blocks):
+            s += [("conv", 128, 1, 1, "leaky"), ("conv", 32, 3, 1, "leaky"), ("route", [-1, -3])]
+        if trans:
+            s += [("conv", trans, 1, 1, "leaky"), ("max", 2, 2)]
+    return s + [("conv", 1000, 1, 0, "linear")] + _CLS_HEAD
+
+
+_EXTRACTION_TRUNK = [
+    ("conv", 64, 7, 1, "leaky", 2), ("max", 2, 2), ("conv", 192, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 128, 1, 1, "leaky"), ("conv", 256, 3, 1, "leaky"), ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"), ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"),
+    ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"), ("conv", 256, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"),
+    ("conv", 512, 1, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 512, 1, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"), ("conv", 512, 1, 1, "leaky"), ("conv", 1024, 3, 1, "leaky"),
+]
+SPECS["resnet50"] = _resnet50()
+SPECS["densenet201"] = _densenet201()
+SPECS["extraction"] = _EXTRACTION_TRUNK + [("conv", 1000, 1, 0, "leaky")] + _CLS_HEAD          # cfg/extraction.cfg
+SPECS["darknet-ref"] = [                                                                         # cfg/darknet.cfg
+    ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("conv", 32, 3, 1, "leaky"), ("max", 2, 2), ("conv", 64, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 128, 3, 1, "leaky"), ("max", 2, 2), ("conv", 256, 3, 1, "leaky"), ("max", 2, 2), ("conv", 512, 3, 1, "leaky"),
+    ("max", 2, 2, 1), ("conv", 1024, 3, 1, "leaky"), ("conv", 1000, 1, 0, "leaky")] + _CLS_HEAD
+SPECS["tiny"] = [                                                                                # cfg/tiny.cfg
+    ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("conv", 32, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 16, 1, 1, "leaky"), ("conv", 128, 3, 1, "leaky"), ("conv", 16, 1, 1, "leaky"), ("conv", 128, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 32, 1, 1, "leaky"), ("conv", 256, 3, 1, "leaky"), ("conv", 32, 1, 1, "leaky"), ("conv", 256, 3, 1, "leaky"), ("max", 2, 2),
+    ("conv", 64, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"), ("conv", 64, 1, 1, "leaky"), ("conv", 512, 3, 1, "leaky"),
+    ("conv", 128, 1, 1, "leaky"), ("conv", 1000, 1, 0, "linear")] + _CLS_HEAD
+SPECS["alexnet"] = [                                                                             # cfg/alexnet.cfg (227x227)
+    ("conv", 96, 11, 0, "relu", 4, 0), ("max", 3, 2, 0), ("conv", 256, 5, 0, "relu"), ("max", 3, 2, 0),
+    ("conv", 384, 3, 0, "relu"), ("conv", 384, 3, 0, "relu"), ("conv", 256, 3, 0, "relu"), ("max", 3, 2, 0),
+    ("connected", 4096, 0, "relu"), ("dropout", 0.5), ("connected", 4096, 0, "relu"), ("dropout", 0.5),
+    ("connected", 1000, 0, "linear"), ("softmax",), ("cost",)]
+_VGG_CONV = ([("conv", 64, 3, 0, "relu")] * 2 + [("max", 2, 2)] + [("conv", 128, 3, 0, "relu")] * 2 + [("max", 2, 2)] +
+             [("conv", 256, 3, 0, "relu")] * 3 + [("max", 2, 2)] + [("conv", 512, 3, 0, "relu")] * 3 + [("max", 2, 2)] +
+             [("conv", 512, 3, 0, "relu")] * 3 + [("max", 2, 2)])
+SPECS["vgg-16"] = [("crop", 224, 224, 0)] + _VGG_CONV + [                                        # cfg/vgg-16.cfg (256x256 in)
+    ("connected", 4096, 0, "relu"), ("dropout", 0.5), ("connected", 4096, 0, "relu"), ("dropout", 0.5),
+    ("connected", 1000, 0, "linear"), ("softmax",), ("cost",)]
+SPECS["strided"] = [("crop", 224, 224, 0), ("conv", 64, 7, 0, "ramp", 2), ("conv", 192, 3, 0, "ramp", 2),      # cfg/strided.cfg
+                    ("conv", 128, 1, 0, "ramp"), ("conv", 256, 3, 0, "ramp", 2), ("conv", 128, 1, 0, "ramp"), ("conv", 256, 3, 0, "ramp"),
+                    ("conv", 128, 1, 0, "ramp"), ("conv", 512, 3, 0, "ramp", 2)] + \
+                   [("conv", 256, 1, 0, "ramp"), ("conv", 512, 3, 0, "ramp")] * 4 + \
+                   [("conv", 256, 1, 0, "ramp"), ("conv", 1024, 3, 0, "ramp", 2), ("conv", 512, 1, 0, "ramp"), ("conv", 1024, 3, 0, "ramp"),
+                    ("max", 3, 2), ("connected", 4096, 0, "ramp"), ("dropout", 0.5), ("connected", 1000, 0, "ramp"), ("softmax",), ("cost",)]
+# cfg/yolov1/yolo-small.cfg: [crop] in front, no batch-norm, three dense layers
+SPECS["yolo-v1-small"] = [("crop", 448, 448, 0)] + [(e[0], e[1], e[2], 0) + tuple(e[4:]) if e[0] == "conv" else e for e in _EXTRACTION_TRUNK] + [
+    ("conv", 1024, 3, 0, "leaky"), ("conv", 1024, 3, 0, "leaky", 2), ("conv", 1024, 3, 0, "leaky"), ("conv", 1024, 3, 0, "leaky"),
+    ("connected", 512, 0, "leaky"), ("connected", 4096, 0, "leaky"), ("dropout", 0.5), ("connected", 1470, 0, "linear"),
+    ("detection", {"classes": 20, "num": 2, "side": 7, "softmax": 0, "sqrt": 1})]
+
+# every activation of activations.h:21-54 outside the four the target cfgs use (strided.cfg is all `ramp`): on
+# matrix-core convolutions, a strided one, a shortcut, and behind a placed (zero-copy) route source
+SPECS["mini-acts"] = [
+    ("conv", 16, 3, 1, "loggy"), ("conv", 16, 3, 1, "relie"), ("conv", 32, 3, 1, "ramp", 2), ("conv", 16, 1, 1, "tanh"),
+    ("conv", 32, 3, 0, "plse"), ("conv", 32, 3, 1, "elu"), ("shortcut", -2, "stair"), ("conv", 16, 1, 1, "hardtan"),
+    ("route", [-1, -3]), ("conv", 32, 3, 1, "lhtan"), ("conv", 30, 1, 0, "linear"),
+    ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]}),
+]
+
 # cfg/yolov1/yolo.cfg: the full YOLOv1 -- 7x7/2 stem, 24 convolutions, a 3x3/2 convolution, a locally connected layer
 # (49 locations x 256 filters x 9216 taps = 462 MB of weights), dropout, one dense layer, the [detection] head
 SPECS["yolo-v1"] = [
@@ -126,7 +203,8 @@ SPECS["yolo-v1"] = [
     ("detection", {"classes": 20, "num": 3, "side": 7, "softmax": 0, "sqrt": 1}),
 ]
 
-DEFAULT_SIZE = {"yolo-v1": 448, "mini-v1-local": 40, "yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32, "tiny-yolo-v1": 448, "mini-v1": 32}
+DEFAULT_SIZE = {"resnet50": 256, "densenet201": 256, "extraction": 224, "darknet-ref": 224, "tiny": 224, "alexnet": 227, "vgg-16": 256,
+                "strided": 256, "yolo-v1-small": 448, "mini-acts": 32, "yolo-v1": 448, "mini-v1-local": 40, "yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32, "tiny-yolo-v1": 448, "mini-v1": 32}
 
 
 def cfg_text(name: str, width: int | None = None, height: int | None = None, batch: int = 1,
@@ -146,7 +224,7 @@ def cfg_text(name: str, width: int | None = None, height: int | None = None, bat
                 out.append("batch_normalize=1")
             out += ["activation=%s" % act, ""]
         elif kind == "max":
-            out += ["[maxpool]", "size=%d" % e[1], "stride=%d" % e[2], ""]
+            out += ["[maxpool]", "size=%d" % e[1], "stride=%d" % e[2]] + (["padding=%d" % e[3]] if len(e) > 3 else []) + [""]
         elif kind == "route":
             out += ["[route]", "layers=" + ",".join(str(i) for i in e[1]), ""]
         elif kind == "reorg":
@@ -209,7 +287,7 @@ def resolve(name_or_spec, width: int, height: int | None = None, channels: int =
                      out_c=filters)
         elif kind == "max":
             size, stride = e[1], e[2]
-            pad = (size - 1) // 2
+            pad = e[3] if len(e) > 3 else (size - 1) // 2
             L.update(type="maxpool", size=size, stride=stride, pad=pad,
                      out_w=(w + 2 * pad) // stride, out_h=(h + 2 * pad) // stride, out_c=c)
         elif kind == "route":

@@ -89,7 +89,12 @@ def test_cfg_parse_matches_oracle_and_zoo(oracle, workdir, name, size, batch):
     on.close()
 
 
-REF_CFGS = {"yolo": ("yolo.cfg", 416), "tiny-yolo-voc": ("tiny-yolo-voc.cfg", 416), "darknet19": ("darknet19_448.cfg", 448)}
+REF_CFGS = {"yolo": ("yolo.cfg", 416), "tiny-yolo-voc": ("tiny-yolo-voc.cfg", 416), "darknet19": ("darknet19_448.cfg", 448),
+            # the reference's other cfg files, restated in zoo.py (classifiers, the YOLOv1 family)
+            "resnet50": ("resnet50.cfg", 256), "densenet201": ("densenet201.cfg", 256), "extraction": ("extraction.cfg", 224),
+            "darknet-ref": ("darknet.cfg", 224), "tiny": ("tiny.cfg", 224), "alexnet": ("alexnet.cfg", 227), "vgg-16": ("vgg-16.cfg", 256),
+            "strided": ("strided.cfg", 256), "yolo-v1": ("yolov1/yolo.cfg", 448), "yolo-v1-small": ("yolov1/yolo-small.cfg", 448),
+            "tiny-yolo-v1": ("yolov1/tiny-yolo.cfg", 448)}
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE_ROOT), reason="reference checkout not present (GPU box)")
@@ -103,6 +108,12 @@ def test_reference_cfg_files_parse_to_the_zoo_tables(workdir, name):
     open(ours, "w").write(zoo.cfg_text(name, size, size, ref_net.batch))
     our_net = darknet.Network.parse_network_cfg(ours)
     assert table_of(ref_net) == table_of(our_net)
+    assert [(ref_net.layer(i).activation, ref_net.layer(i).noadjust) for i in range(ref_net.n)] == \
+           [(our_net.layer(i).activation, our_net.layer(i).noadjust) for i in range(our_net.n)]
+    if name not in ("yolo", "tiny-yolo-voc", "darknet19"):
+        ref_net.free()
+        our_net.free()
+        return
     if name == "tiny-yolo-voc":
         assert ref_net.batch == 8          # batch=64 / subdivisions=8 (cfg/tiny-yolo-voc.cfg:2-3)
     a = np.ctypeslib.as_array(ref_net.last.biases, shape=(2 * ref_net.last.n,)) if name != "darknet19" else None
