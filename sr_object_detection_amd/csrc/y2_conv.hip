@@ -113,10 +113,20 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         unsigned m = 0;
         if (live && r < a.npix && (BM % RP == 0 || sr + q * RP < BM)) {
             if (KS == 1) m = 1u;
-            else {
+            else if (KS == 3) {
                 // bit kh*3+kw = tap inside the image: (column pattern) x (row pattern spread 3 bits apart), no carries
                 const unsigned xm = (px > 0 ? 1u : 0u) | 2u | (px < a.W - 1 ? 4u : 0u);
                 const unsigned ym = (py > 0 ? 1u : 0u) | 8u | (py < a.H - 1 ? 64u : 0u);
+                m = xm * ym;
+            } else {
+                // same product for any odd size with KS*KS <= 32 taps (5x5: alexnet.cfg)
+                static_assert(KS * KS <= 32, "one mask bit per tap");
+                unsigned xm = 0, ym = 0;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    if (px + k - KS / 2 >= 0 && px + k - KS / 2 < a.W) xm |= 1u << k;
+                    if (py + k - KS / 2 >= 0 && py + k - KS / 2 < a.H) ym |= 1u << (k * KS);
+                }
                 m = xm * ym;
             }
         }
@@ -149,9 +159,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // (zeros, no memory traffic) -- cheaper than a branch, which would split the scheduling region.
     auto load_slice = [&]() {
         int delta = 0;        // float offset of the tap relative to the centre pixel
-        if (KS == 3) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            delta = ((kh - 1) * a.W + (kw - 1)) * a.ldx;
+        if (KS > 1) {
+            const int kh = tap / KS, kw = tap - kh * KS;
+            delta = ((kh - KS / 2) * a.W + (kw - KS / 2)) * a.ldx;
         }
         const unsigned add = (unsigned)((delta + c0) * 4);
 #pragma unroll
@@ -739,12 +749,15 @@ static Variant g_variants[] = {
     VAR(128, 64, 16, 3, 2, 2),  VAR(128, 64, 16, 1, 2, 2),
     VAR(64, 64, 16, 3, 2, 2),   VAR(64, 64, 16, 1, 2, 2),
     VAR(128, 32, 16, 3, 4, 1),  VAR(128, 32, 16, 1, 4, 1),
+    // 5x5 (alexnet.cfg)
+    VAR(128, 128, 32, 5, 2, 2), VAR(64, 64, 32, 5, 2, 2),
+    VAR(128, 128, 16, 5, 2, 2), VAR(64, 64, 16, 5, 2, 2),
 };
 
 static bool mfma_ok(const y2h_conv *d)
 {
     if (d->x_f16 || d->y_f16) return false;       // the fp32 matrix-core kernel reads and writes fp32 only
-    if (!(d->size == 1 || d->size == 3)) return false;
+    if (!(d->size == 1 || d->size == 3 || d->size == 5)) return false;
     if (d->stride < 1 || d->pad != d->size / 2) return false;
     if (d->c % 16 != 0 || d->ldx % 4 != 0) return false;
     if (d->out_h != (d->h + 2 * d->pad - d->size) / d->stride + 1 || d->out_w != (d->w + 2 * d->pad - d->size) / d->stride + 1) return false;

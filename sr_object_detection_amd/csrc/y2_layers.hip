@@ -6,6 +6,15 @@
 #include <float.h>
 #include <stdlib.h>
 
+// the four in-kernel activations, with the reference's arithmetic (activations.h:35-41: leaky and logistic in double)
+__device__ __forceinline__ float activate_ref(float v, int act)
+{
+    if (act == Y2H_ACT_LEAKY) v = (v > 0) ? v : (float)(.1 * (double)v);
+    else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));
+    else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);
+    return v;
+}
+
 // ---------------------------------------------------------------------------
 // maxpool  (src_yolo2/maxpool_layer.c:79-114; CUDA twin maxpool_layer_kernels.cu:10)
 // window origin = -pad + o*stride, out-of-image taps read as -FLT_MAX, strict '>'
@@ -186,8 +195,12 @@ __device__ __forceinline__ void softmax_seq(const float *in, int n, float temp, 
 // One workgroup per row.  The maximum (order-independent) and the double-precision exp of every
 // element (the expensive part) are done by all lanes; only the fp32 running sum -- whose order the
 // reference fixes -- is walked by one lane, so the result is still bit-identical to softmax_seq.
+// LDS = true: the exponentials also stay in LDS (n floats of dynamic shared memory), so the one lane that walks the
+// running sum reads them at LDS rather than at global-memory latency (1000 classes: 69 -> a few microseconds).
+template <bool LDS>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float *x, float *y, long rows, int n, float temp)
 {
+    extern __shared__ float s_exp[];
     __shared__ float s_red[256];
     __shared__ float s_val;
     const float *in = x + (long)blockIdx.x * n;
@@ -202,22 +215,29 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float *x, float
         __syncthreads();
     }
     largest = s_red[0];
-    for (int i = t; i < n; i += 256) out[i] = (float)exp((double)(in[i] / temp - largest / temp));
+    for (int i = t; i < n; i += 256) {
+        const float e = (float)exp((double)(in[i] / temp - largest / temp));
+        if (LDS) s_exp[i] = e; else out[i] = e;
+    }
     __syncthreads();
     if (t == 0) {
         float sum = 0.f;
-        for (int i = 0; i < n; ++i) sum += out[i];
+        if (LDS) for (int i = 0; i < n; ++i) sum += s_exp[i];
+        else for (int i = 0; i < n; ++i) sum += out[i];
         s_val = sum;
     }
     __syncthreads();
     const float sum = s_val;
-    for (int i = t; i < n; i += 256) out[i] /= sum;
+    for (int i = t; i < n; i += 256) out[i] = (LDS ? s_exp[i] : out[i]) / sum;
 }
 
 extern "C" int y2h_softmax_rows(const float *x, float *y, long rows, int n, float temp, y2h_stream s)
 {
     if (rows <= 0 || n <= 0) return Y2H_EINVAL;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, S(s), x, y, rows, n, temp);
+    if ((size_t)n * sizeof(float) <= 48 * 1024)
+        hipLaunchKernelGGL(softmax_rows_kernel<true>, dim3((unsigned)rows), dim3(256), (size_t)n * sizeof(float), S(s), x, y, rows, n, temp);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<false>, dim3((unsigned)rows), dim3(256), 0, S(s), x, y, rows, n, temp);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }
@@ -369,11 +389,35 @@ __global__ __launch_bounds__(256) void shortcut_kernel(const float *__restrict__
     }
 }
 
+// the common case -- both operands of the same shape (every [shortcut] of resnet50.cfg but the three that change width),
+// channels a multiple of 4: 16-byte loads and stores, no coordinate decode
+__global__ __launch_bounds__(256) void shortcut_same_kernel(const float *__restrict__ in, int ld_in, const float *__restrict__ add,
+                                                            int ld_add, float *__restrict__ out, int ld_out, int c4, int act, long total)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long pix = idx / c4;
+        const int k = (int)(idx - pix * c4) * 4;
+        const float4 a = *(const float4 *)(in + pix * ld_in + k), b = *(const float4 *)(add + pix * ld_add + k);
+        float4 r;
+        r.x = activate_ref(a.x + b.x, act); r.y = activate_ref(a.y + b.y, act);
+        r.z = activate_ref(a.z + b.z, act); r.w = activate_ref(a.w + b.w, act);
+        *(float4 *)(out + pix * ld_out + k) = r;
+    }
+}
+
 extern "C" int y2h_shortcut(const float *in, int ld_in, const float *add, int ld_add, float *out, int ld_out, int batch,
                             int w1, int h1, int c1, int w2, int h2, int c2, int activation, y2h_stream s)
 {
     if (!in || !add || !out || batch <= 0 || w1 <= 0 || h1 <= 0 || c1 <= 0 || w2 <= 0 || h2 <= 0 || c2 <= 0) return Y2H_EINVAL;
     if (ld_in < c2 || ld_out < c2 || ld_add < c1) return Y2H_EINVAL;
+    if (w1 == w2 && h1 == h2 && c1 == c2 && c2 % 4 == 0 && ld_in % 4 == 0 && ld_add % 4 == 0 && ld_out % 4 == 0 &&
+        (((uintptr_t)in | (uintptr_t)add | (uintptr_t)out) & 15) == 0) {
+        const long total4 = (long)batch * h2 * w2 * (c2 / 4);
+        hipLaunchKernelGGL(shortcut_same_kernel, dim3(y2h_grid(total4, 256)), dim3(256), 0, S(s), in, ld_in, add, ld_add, out, ld_out,
+                           c2 / 4, activation, total4);
+        Y2H_LAUNCH_CHECK();
+        return Y2H_OK;
+    }
     int stride = w1 / w2, sample = w2 / w1;
     if (stride != h1 / h2 || sample != h2 / h1) return Y2H_EINVAL;      /* the reference asserts this (blas.c:61-62) */
     if (stride < 1) stride = 1;
@@ -452,13 +496,6 @@ extern "C" int y2h_batchnorm(const float *x, int ldx, float *y, int ldy, long pi
 // local_ref_kernel is the strict-mode form: one thread per output value, bias first, taps in the reference's
 // k = (c, kh, kw) order, product and sum rounded separately -- the arithmetic of gemm_nn (gemm.c:74-88).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float activate_ref(float v, int act)
-{
-    if (act == Y2H_ACT_LEAKY) v = (v > 0) ? v : (float)(.1 * (double)v);
-    else if (act == Y2H_ACT_LOGISTIC) v = (float)(1. / (1. + exp(-(double)v)));
-    else if (act == Y2H_ACT_RELU) v = v * (float)(v > 0);
-    return v;
-}
 
 // every activation of activations.h:21-54, with the reference's own promotion rules (float x, double constants, the
 // result rounded to float on return)
