@@ -29,11 +29,31 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def usable_cores() -> int:
+    """CPU threads this process may really use: the cgroup quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
         L = C.CDLL(LIB_PATH)
+        # OpenMP defaults to one thread per hardware thread of the HOST; inside a container with a CPU quota (the GPU
+        # box: 16 of a few hundred) the oracle's many small parallel loops then spend seconds spinning.  Results do not
+        # depend on the thread count (row-parallel only), so cap it at what this process may use.
+        if "OMP_NUM_THREADS" not in os.environ:
+            try:
+                C.CDLL("libgomp.so.1").omp_set_num_threads(max(1, min(usable_cores(), 16)))
+            except OSError:
+                pass
         fp = C.POINTER(C.c_float)
         L.orc_parse_cfg.restype = C.c_void_p
         L.orc_parse_cfg.argtypes = [C.c_char_p]
