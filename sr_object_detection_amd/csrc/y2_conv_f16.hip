@@ -475,6 +475,169 @@ static VariantH g_variants_h[] = {
     VARH(64, 64, 32, 3, 2, 2, 2, true, false),   VARH(64, 64, 32, 1, 2, 2, 2, true, false),
 };
 
+// ---------------------------------------------------------------------------
+// 3x3 convolution with 32 input channels (the 32 -> 64 layer of every Darknet-19 trunk), weights stationary.
+//
+// K = 288 is nine slices of the generic kernel, each with a barrier and a staging round for two MFMA steps of work:
+// that layer ran at 340 TFLOP/s (13 % of the darknet19_448 b128 step).  Here nothing is staged inside the K loop:
+//   * the filter fragments of this lane -- [filter tile][tap*2 + k-step], 18 x 16 bytes per 32 filters -- are loaded
+//     once per kernel and stay in registers (144 VGPRs for 64 filters);
+//   * a workgroup walks 16x16-pixel output tiles; the 18x18-pixel input patch of the NEXT tile (64 bytes per pixel) is
+//     fetched into registers while the current one multiplies and written to the other LDS buffer afterwards: one
+//     barrier per tile of 144 MFMAs per wave;
+//   * an MFMA row tile is a 2 x 16 pixel strip in pool-major order (row r = 4*window + corner), read straight from the
+//     patch with one ds_read_b128 per tap and k-step, shared by both filter tiles: 0.5 LDS reads per MFMA (the generic
+//     kernel needs 0.75).  Pixel pitch 80 B and row pitch 1664 B make those reads bank-conflict free.
+// ---------------------------------------------------------------------------
+template <int NF, bool POOL>
+__global__ __launch_bounds__(256, 2) void conv_c32_f16_kernel(ConvK a)
+{
+    constexpr int PW = 18, PIX_B = 80, ROW_B = 1664, BUF_B = PW * ROW_B;
+    constexpr int NCH = PW * PW * 4;                 // 16-byte chunks of one patch
+    constexpr int NP = (NCH + 255) / 256;            // staging passes
+    extern __shared__ __attribute__((aligned(16))) unsigned char c32_smem[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+
+    f16x8 bw[NF][18];
+    float alpha[NF], beta[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int co = 32 * j + li;
+        const bool cok = co < a.Cout;
+        alpha[j] = cok ? a.alpha[co] : 0.f;
+        beta[j] = cok ? a.beta[co] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 18; ++kk) {
+            const unsigned off = cok ? (unsigned)((co * 288 + (kk >> 1) * 32 + (kk & 1) * 16 + 8 * lh) * 2) : a.wbytes;
+            bw[j][kk] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+        }
+    }
+
+    // staging role: chunk q = t + 256*p of the patch -> patch pixel (py, px), 16-byte part
+    const int ldxB = a.ldx * 2;
+    int s_lds[NP], s_rel[NP], s_yx[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int q = t + 256 * p;
+        const int pixel = q >> 2, part = q & 3;
+        const int py = pixel / PW, px = pixel - py * PW;
+        s_lds[p] = py * ROW_B + px * PIX_B + part * 16;
+        s_rel[p] = ((py - 1) * a.W + (px - 1)) * ldxB + part * 16;
+        s_yx[p] = q < NCH ? (py << 8) | px : -1;
+    }
+    const int tiles_x = a.W >> 4, tpi = (a.H >> 4) * tiles_x;
+    const int ntiles = a.batch * tpi;
+    u32x4 sreg[NP];
+    auto load_tile = [&](int tile) {
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int oy0 = (rem / tiles_x) << 4, ox0 = (rem - (rem / tiles_x) * tiles_x) << 4;
+        const int base = ((n * a.H + oy0) * a.W + ox0) * ldxB;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int iy = oy0 - 1 + (s_yx[p] >> 8), ix = ox0 - 1 + (s_yx[p] & 255);
+            const bool ok = s_yx[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            sreg[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)(base + s_rel[p]) : a.xbytes, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (s_yx[p] >= 0) *(u32x4 *)(c32_smem + buf * BUF_B + s_lds[p]) = sreg[p];
+    };
+
+    // this lane's pixel inside a 2 x 16 strip: window li>>2, corner li&3
+    const int a_off = ((li >> 1) & 1) * ROW_B + (2 * (li >> 2) + (li & 1)) * PIX_B + lh * 16;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    _Float16 *yh = (_Float16 *)a.y;
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile < ntiles) { load_tile(tile); store_tile(0); }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int oy0 = (rem / tiles_x) << 4, ox0 = (rem - (rem / tiles_x) * tiles_x) << 4;
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+            const int rp = 2 * wv + rpi;                       // strip = output rows oy0 + 2rp, +1
+            const unsigned char *ap = c32_smem + cur * BUF_B + 2 * rp * ROW_B + a_off;
+            f32x16 acc[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const f16x8 af = *(const f16x8 *)(ap + kh * ROW_B + kw * PIX_B + ks * 32);
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bw[j][(kh * 3 + kw) * 2 + ks], acc[j], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int co = 32 * j + li;
+                if (POOL) {
+                    const size_t prow = ((size_t)n * Hp + (oy0 >> 1) + rp) * Wp + (ox0 >> 1);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], a.act);
+#pragma unroll
+                        for (int u = 1; u < 4; ++u) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + u], alpha[j], beta[j], a.act));
+                        if (co < a.Cout) yh[(prow + 2 * g + lh) * a.ldy + co] = (_Float16)m;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;            // GEMM row = 4*window + corner
+                        const int oy = oy0 + 2 * rp + ((rr >> 1) & 1), ox = ox0 + 2 * (rr >> 2) + (rr & 1);
+                        if (co < a.Cout)
+                            yh[(((size_t)n * a.H + oy) * a.W + ox) * a.ldy + co] = (_Float16)epilogue_fast(acc[j][r], alpha[j], beta[j], a.act);
+                    }
+                }
+            }
+        }
+        if (next < ntiles) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+}
+
+static bool c32_ok(const y2h_conv *d)
+{
+    if (!d->x_f16 || !d->y_f16 || d->x_halo || getenv("Y2_NO_C32")) return false;
+    if (d->size != 3 || d->stride != 1 || d->pad != 1 || d->c != 32 || d->n > 64) return false;
+    if (d->out_h != d->h || d->out_w != d->w || (d->h & 15) || (d->w & 15) || d->ldx % 8 != 0) return false;
+    if (((uintptr_t)d->x | (uintptr_t)d->w_packed) % 16 != 0) return false;
+    const double xbytes = (double)d->batch * d->h * d->w * d->ldx * 2.0;
+    return xbytes < 2147483000.0 && d->w_packed != nullptr;
+}
+
+static int c32_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
+{
+    if (!d->alpha || !d->beta) return Y2H_EINVAL;
+    a.w = d->w_packed;
+    a.alpha = d->alpha; a.beta = d->beta;
+    a.npix = d->batch * d->h * d->w;
+    a.xbytes = (unsigned)((size_t)d->batch * d->h * d->w * d->ldx * 2);
+    a.wbytes = (unsigned)((size_t)d->n * 288 * 2);
+    const int nf = d->n <= 32 ? 1 : 2;
+    void (*fn)(ConvK) = nf == 1 ? (a.pool ? conv_c32_f16_kernel<1, true> : conv_c32_f16_kernel<1, false>)
+                                : (a.pool ? conv_c32_f16_kernel<2, true> : conv_c32_f16_kernel<2, false>);
+    const size_t lds = (size_t)2 * 18 * 1664;
+    Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long tiles = (long)d->batch * (d->h >> 4) * (d->w >> 4);
+    long grid = tiles < 512 ? tiles : 512;               // two workgroups per CU, tiles are grid-strided
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, S(s), a);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
 bool y2_f16_conv_ok(const y2h_conv *d)
 {
     if (!d->x_f16) return false;
@@ -532,12 +695,14 @@ static VariantH *pick_h(const y2h_conv *d)
 
 const char *y2_f16_conv_variant(const y2h_conv *d)
 {
+    if (c32_ok(d)) return "conv_c32_f16_16x16";
     VariantH *v = y2_f16_conv_ok(d) ? pick_h(d) : nullptr;
     return v ? v->name : nullptr;
 }
 
 int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
 {
+    if (c32_ok(d)) return c32_launch(d, a, s);
     VariantH *v = pick_h(d);
     if (!v || !d->alpha || !d->beta) return Y2H_EINVAL;
     a.w = d->w_packed;

@@ -57,6 +57,34 @@ def test_f16_conv_with_fused_maxpool_is_exact(oracle, workdir, cin, filters, siz
     on.close()
 
 
+@pytest.mark.parametrize("filters,size,batch,act", [(64, 32, 2, "linear"), (64, 48, 3, "leaky"), (48, 16, 1, "linear"), (24, 32, 2, "linear"),
+                                                    (64, 64, 5, "linear")])
+def test_f16_c32_weights_stationary_kernel_is_exact(oracle, workdir, filters, size, batch, act):
+    """the 32-channel 3x3 kernel (weights in registers, 18x18 input patches through LDS, 2x16-pixel MFMA strips in
+    pool-major order): with and without the fused maxpool, one and two filter tiles, partial filter tiles, image
+    borders on every side of a 16x16 tile, more tiles than workgroups per image row"""
+    spec = [("conv", 32, 3, 0, "linear"), ("conv", filters, 3, 0, act), ("max", 2, 2)]
+    cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 9700 + filters + size)
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    assert np.abs(on.layer_output(0)).max() <= 2048 and np.abs(on.layer_output(1)).max() < 60000
+    for fuse in (True, False):
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        net.set_half(True)
+        net.set_fusion(fuse)
+        out = net.network_predict(x)
+        assert net.layer_kernel(1) == "conv_c32_f16_16x16" + ("+maxpool2" if fuse else ""), net.layer_kernel(1)
+        if act == "linear":
+            assert np.array_equal(out, _as_half(ref))
+            if not fuse:
+                assert np.array_equal(net.pull_layer_output(1), _as_half(on.layer_output(1)))
+        else:       # leaky: .1*x is evaluated in fp32 here and in double by the reference -- one half ulp at most
+            assert np.abs(out - ref).max() <= np.abs(ref).max() * 2.0 ** -10
+        net.free()
+    on.close()
+
+
 def test_f16_darknet19_classifier_top5(workdir):
     g = load_golden("darknet19_224_b1")
     cfg, wts, x = materialize(workdir, "darknet19", 224, 1, int(g["seed"]), float(g["head_gain"]))
@@ -65,7 +93,7 @@ def test_f16_darknet19_classifier_top5(workdir):
     net.set_half(True)
     out = net.network_predict(x)
     kernels = [net.layer_kernel(i) for i in range(net.n)]
-    assert sum(k.startswith("conv_mfma_f16") for k in kernels) == 18, kernels
+    assert sum(k.startswith(("conv_mfma_f16", "conv_c32_f16")) for k in kernels) == 18, kernels
     want = g["out"]
     err = float(np.abs(out - want).max())
     print("darknet19 fp16 vs fp32 CPU reference: max |dp| = %.3e" % err)
