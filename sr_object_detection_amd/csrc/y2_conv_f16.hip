@@ -551,6 +551,10 @@ __global__ __launch_bounds__(256, 2) void conv_c32_f16_kernel(ConvK a)
     const int a_off = ((li >> 1) & 1) * ROW_B + (2 * (li >> 2) + (li & 1)) * PIX_B + lh * 16;
     const int Hp = a.H >> 1, Wp = a.W >> 1;
     _Float16 *yh = (_Float16 *)a.y;
+    // pooled outputs leave as 16-byte stores: a strip's 8 windows x 64 filters are transposed through a wave-private
+    // 1.1 KB scratch behind the two patch buffers (LDS operations of one wave execute in order: no barrier)
+    constexpr int ES_B = 144;                        // scratch row: 64 filters x 2 B + 16 B
+    unsigned char *es = c32_smem + 2 * BUF_B + wv * 8 * ES_B;
 
     int tile = blockIdx.x, cur = 0;
     if (tile < ntiles) { load_tile(tile); store_tile(0); }
@@ -580,6 +584,21 @@ __global__ __launch_bounds__(256, 2) void conv_c32_f16_kernel(ConvK a)
                         for (int j = 0; j < NF; ++j)
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bw[j][(kh * 3 + kw) * 2 + ks], acc[j], 0, 0, 0);
                     }
+            if (POOL && a.vec_store) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], a.act);
+#pragma unroll
+                        for (int u = 1; u < 4; ++u) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + u], alpha[j], beta[j], a.act));
+                        *(_Float16 *)(es + (2 * g + lh) * ES_B + (32 * j + li) * 2) = (_Float16)m;
+                    }
+                const u32x4 v = *(const u32x4 *)(es + (lane >> 3) * ES_B + (lane & 7) * 16);
+                const size_t prow = ((size_t)n * Hp + (oy0 >> 1) + rp) * Wp + (ox0 >> 1) + (lane >> 3);
+                if ((lane & 7) * 8 < a.Cout) *(u32x4 *)&yh[prow * a.ldy + (lane & 7) * 8] = v;
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 const int co = 32 * j + li;
@@ -629,7 +648,8 @@ static int c32_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     const int nf = d->n <= 32 ? 1 : 2;
     void (*fn)(ConvK) = nf == 1 ? (a.pool ? conv_c32_f16_kernel<1, true> : conv_c32_f16_kernel<1, false>)
                                 : (a.pool ? conv_c32_f16_kernel<2, true> : conv_c32_f16_kernel<2, false>);
-    const size_t lds = (size_t)2 * 18 * 1664;
+    const size_t lds = (size_t)2 * 18 * 1664 + 4 * 8 * 144;
+    a.vec_store = d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !getenv("Y2_C32_SCALAR");
     Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     long tiles = (long)d->batch * (d->h >> 4) * (d->w >> 4);
     long grid = tiles < 512 ? tiles : 512;               // two workgroups per CU, tiles are grid-strided
@@ -752,6 +772,7 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(ConvK a)
     const long nwaves = (long)gridDim.x * 4;
     const long ntiles = ((long)a.npix + 31) / 32;
     const int W2 = a.W + 2, H2 = a.H + 2, HW = a.H * a.W;
+    __shared__ __attribute__((aligned(16))) unsigned char first_es[4 * 8 * 144];
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
 
     // taps of this lane: step s -> taps 4s+2lh, 4s+2lh+1 (>= 9: none)
@@ -838,6 +859,24 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(ConvK a)
         }
         const long prow = tile * 32 + 4 * lh;
         _Float16 *yh = (_Float16 *)a.y;
+        if (a.pool && a.vec_store) {
+            // half outputs as 16-byte stores: the tile's 8 pooled pixels x 32*NT filters go through a wave-private LDS
+            // scratch (2-byte stores cost several MFMA times each; LDS operations of one wave execute in order)
+            unsigned char *es = first_es + (threadIdx.x >> 6) * 8 * 144;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], a.act);
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + t], alpha[j], beta[j], a.act));
+                    *(_Float16 *)(es + (2 * g + lh) * 144 + (32 * j + li) * 2) = (_Float16)m;
+                }
+            const u32x4 v = *(const u32x4 *)(es + (lane >> 3) * 144 + (lane & 7) * 16);
+            const long pr = tile * 8 + (lane >> 3);
+            if ((lane & 7) * 8 < a.Cout && pr * 4 < a.npix) *(u32x4 *)&yh[(size_t)pr * a.ldy + (lane & 7) * 8] = v;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int co = j * 32 + li;
@@ -897,6 +936,7 @@ int y2_f16_first_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     a.npix = d->batch * d->h * d->w;
     a.xbytes = (unsigned)((size_t)d->batch * (d->h + 2) * (d->w + 2) * 8);
     const long ntiles = ((long)a.npix + 31) / 32;
+    a.vec_store = d->y_f16 && d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !getenv("Y2_C32_SCALAR");
     long blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;          // tiles are grid-strided
     if (d->n <= 32) hipLaunchKernelGGL(conv_first_f16_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
