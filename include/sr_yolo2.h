@@ -261,6 +261,11 @@ void y2_set_strict(network *net, int strict);
 /* conv -> 2x2/2 maxpool pairs are fused by default (the conv pools in its epilogue and the
  * full-resolution activation is never stored); 0 turns that off, e.g. to inspect every layer. */
 void y2_set_fusion(network *net, int on);
+/* Record the forward pass's kernel launches into a hipGraph at the next call and replay it afterwards (one
+ * hipGraphLaunch instead of 20-60 launches; for batch-1 callers such as test_detector_img).  The graph is tied to
+ * the plan and to the input pointer: a resize / set_batch / mode switch or a different device input re-records.
+ * Off by default; env Y2_GRAPH=1 turns it on for every network.  Ignored in strict mode and while layer timing is on. */
+void y2_set_graph(network *net, int on);
 /* The packed, kernel-layout weight arena (one allocation; what a multi-GPU launcher broadcasts). */
 int y2_weights_arena(network *net, void **dev_ptr, size_t *bytes);
 /* fp16 storage mode (no reference counterpart; BASELINE configs[4]): activations and packed weights are

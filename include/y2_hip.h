@@ -46,6 +46,7 @@ extern "C" {
 
 typedef void *y2h_stream;   /* hipStream_t */
 typedef void *y2h_event;    /* hipEvent_t */
+typedef void *y2h_graph;    /* hipGraphExec_t */
 
 /* activation codes (src_yolo2/activations.h:7).  0-3 are the ones the target cfgs use and every kernel's epilogue
  * applies in place; the others only exist as the separate pass y2h_activate_array (the engine then runs the
@@ -79,6 +80,14 @@ int         y2h_event_create(y2h_event *e);
 int         y2h_event_destroy(y2h_event e);
 int         y2h_event_record(y2h_event e, y2h_stream s);
 int         y2h_event_elapsed_ms(y2h_event start, y2h_event stop, float *ms);   /* syncs on stop */
+
+/* ---- hipGraph capture of a kernel sequence on a stream (replaces nothing in the reference: its GPU path launches
+ * every kernel from the host each call) ---- */
+int  y2h_graph_begin(y2h_stream s);                   /* start recording what is enqueued on s (nothing executes) */
+int  y2h_graph_end(y2h_stream s, y2h_graph *out);      /* stop recording, instantiate */
+void y2h_graph_abort(y2h_stream s);                   /* leave capture mode after an error, keep nothing */
+int  y2h_graph_launch(y2h_graph g, y2h_stream s);
+int  y2h_graph_destroy(y2h_graph g);
 
 /* ---- layout ---- */
 /* [n][c][h][w] -> [n][h][w][ld] (channels 0..c-1 of each pixel row) and back */

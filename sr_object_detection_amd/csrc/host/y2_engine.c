@@ -42,6 +42,7 @@ int y2_engine_create(network *net)
     e->weights_dirty = 1;
     e->strict = (st && atoi(st) != 0) ? 1 : 0;
     e->fusion = getenv("Y2_NO_FUSE") ? 0 : 1;
+    { const char *g = getenv("Y2_GRAPH"); e->graph_on = (g && atoi(g) != 0) ? 1 : 0; }
     { const char *hf = getenv("Y2_FP16"); e->half = (hf && atoi(hf) != 0) ? 1 : 0; }
     e->n_layers = net->n;
     e->out_layer = y2_out_layer(net);
@@ -98,6 +99,7 @@ static void free_plan(network *net)
         d->fused_pool = 0; d->fused_into = -1;
         d->out_half = 0;
     }
+    if (e->graph) { y2h_graph_destroy(e->graph); e->graph = NULL; e->graph_src = NULL; }
     y2h_free(e->d_in_nchw); e->d_in_nchw = NULL;
     y2h_free(e->d_in_nhwc); e->d_in_nhwc = NULL;
     y2h_free(e->d_out_nchw); e->d_out_nchw = NULL;
@@ -796,14 +798,35 @@ static int ensure_built(network *net)
 /* ------------------------------------------------------------------ */
 /* forward                                                             */
 /* ------------------------------------------------------------------ */
+static int enqueue_forward(network *net, const float *d_input_nchw);
+
+/* One forward pass = a fixed sequence of 20-60 kernel launches with fixed arguments as long as the plan and the input
+ * pointer stay the same.  At batch 1 (the Kinect application's mode) most of them run for 5-30 us, the same order as
+ * the host-side cost of a launch; with y2_set_graph the sequence is captured into a hipGraph at the first call and
+ * replayed with one hipGraphLaunch afterwards.  A new input pointer re-records; a new plan drops the graph. */
 int y2_engine_forward(network *net, const float *d_input_nchw)
 {
     y2_engine *e;
-    int i, k;
     if (ensure_built(net) != 0) return -1;
     e = y2_engine_of(net);
     if (net->c <= 0 || net->h <= 0 || net->w <= 0) { y2_fail("network input must be an image (h,w,c > 0)"); return -1; }
     if (!d_input_nchw) d_input_nchw = e->d_in_nchw;     /* filled by y2_ingest_u8 */
+    if (!e->graph_on || e->timing || e->strict) return enqueue_forward(net, d_input_nchw);
+    if (!e->graph || e->graph_src != d_input_nchw) {
+        if (e->graph) { y2h_graph_destroy(e->graph); e->graph = NULL; }
+        HIPCALL(y2h_graph_begin(e->stream));
+        if (enqueue_forward(net, d_input_nchw) != 0) { y2h_graph_abort(e->stream); return -1; }
+        if (y2h_graph_end(e->stream, &e->graph) != 0) { e->graph = NULL; y2_fail("hipGraph capture of the forward pass failed: %s", y2h_last_error()); return -1; }
+        e->graph_src = d_input_nchw;
+    }
+    HIPCALL(y2h_graph_launch(e->graph, e->stream));
+    return 0;
+}
+
+static int enqueue_forward(network *net, const float *d_input_nchw)
+{
+    y2_engine *e = y2_engine_of(net);
+    int i, k;
     if (e->in_halo == 2)
         HIPCALL(y2h_nchw_to_nhwc4_halo_f16(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, e->stream));
     else if (e->in_halo)
@@ -1014,6 +1037,14 @@ void y2_set_fusion(network *net, int on)
 {
     y2_engine *e = y2_engine_of(net);
     if (e) e->fusion = on ? 1 : 0;
+}
+
+void y2_set_graph(network *net, int on)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (!e) return;
+    e->graph_on = on ? 1 : 0;
+    if (!on && e->graph) { y2h_graph_destroy(e->graph); e->graph = NULL; e->graph_src = NULL; }
 }
 
 void y2_set_timing(network *net, int on)

@@ -52,6 +52,10 @@ typedef struct y2_engine {
     int half, built_half;      /* fp16 storage requested (y2_set_half) / state of the current plan */
     int in_halo;               /* the NHWC copy of the input carries a zero border (2: the half NHWC4 form) */
     int in_halo_px;            /* its width in pixels: 1 for the 3x3 first-layer kernels, the padding for the stem kernel */
+    /* hipGraph replay of the forward launch sequence (y2_set_graph): recorded for one input pointer, dropped with the plan */
+    int graph_on;
+    y2h_graph graph;
+    const float *graph_src;
     /* plan state */
     int built;
     int built_batch, built_w, built_h, built_strict;

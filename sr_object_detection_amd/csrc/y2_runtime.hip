@@ -72,6 +72,30 @@ extern "C" int y2h_stream_destroy(y2h_stream s) { if (s) Y2H_CHECK(hipStreamDest
 extern "C" int y2h_stream_sync(y2h_stream s) { Y2H_CHECK(hipStreamSynchronize(S(s))); return Y2H_OK; }
 extern "C" int y2h_device_sync(void) { Y2H_CHECK(hipDeviceSynchronize()); return Y2H_OK; }
 
+// ---- hipGraph: a launch-bound kernel sequence (batch-1 inference: ~30 launches of 5-30 us) recorded once, replayed
+// with one call ----
+extern "C" int y2h_graph_begin(y2h_stream s) { Y2H_CHECK(hipStreamBeginCapture(S(s), hipStreamCaptureModeThreadLocal)); return Y2H_OK; }
+extern "C" int y2h_graph_end(y2h_stream s, y2h_graph *out)
+{
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    Y2H_CHECK(hipStreamEndCapture(S(s), &g));
+    hipError_t err = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    Y2H_CHECK(err);
+    *out = (y2h_graph)ex;
+    return Y2H_OK;
+}
+// abandon a capture after an error inside it (the stream leaves capture mode; nothing is kept)
+extern "C" void y2h_graph_abort(y2h_stream s)
+{
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(S(s), &g) == hipSuccess && g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+}
+extern "C" int y2h_graph_launch(y2h_graph g, y2h_stream s) { Y2H_CHECK(hipGraphLaunch((hipGraphExec_t)g, S(s))); return Y2H_OK; }
+extern "C" int y2h_graph_destroy(y2h_graph g) { if (g) Y2H_CHECK(hipGraphExecDestroy((hipGraphExec_t)g)); return Y2H_OK; }
+
 extern "C" int y2h_event_create(y2h_event *e)
 {
     hipEvent_t ev;

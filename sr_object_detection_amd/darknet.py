@@ -173,6 +173,7 @@ def lib():
     L.y2_set_strict.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_half.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_fusion.argtypes = [C.POINTER(CNetwork), C.c_int]
+    L.y2_set_graph.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_timing.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_layer_times_ms.argtypes = [CNetwork, C.c_void_p, C.c_int]
     L.y2_layer_kernel.restype = C.c_char_p
@@ -377,6 +378,10 @@ class Network:
 
     def set_fusion(self, on: bool) -> None:
         lib().y2_set_fusion(C.byref(self.net), 1 if on else 0)
+
+    def set_graph(self, on: bool) -> None:
+        """replay the forward pass from a hipGraph (include/sr_yolo2.h y2_set_graph)"""
+        lib().y2_set_graph(C.byref(self.net), 1 if on else 0)
 
     def set_timing(self, on: bool) -> None:
         lib().y2_set_timing(C.byref(self.net), 1 if on else 0)

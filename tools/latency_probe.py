@@ -49,9 +49,17 @@ def main():
         "y2_detect_u8(640x480 BGRA)": med_ms(lambda: net.detect_u8(cam_u8, 0.24, 0.1), iters),
         "forward_device+detect_resident": med_ms(lambda: (net.forward_device(d_x.data_ptr()), net.detect_resident(0.24, 0.1)), iters),
     }
-    print("%s %dx%d batch 1 (median of %d calls, ms):" % (name, size, size, iters))
+    net.set_graph(True)
+    res_g = {
+        "network_predict": med_ms(lambda: net.network_predict(x), iters),
+        "test_detector_img(net-sized)": med_ms(lambda: net.test_detector_img(x[0], 0.24), iters),
+        "test_detector_img(640x480x4)": med_ms(lambda: net.test_detector_img(cam, 0.24), iters),
+        "y2_detect_u8(640x480 BGRA)": med_ms(lambda: net.detect_u8(cam_u8, 0.24, 0.1), iters),
+        "forward_device+detect_resident": med_ms(lambda: (net.forward_device(d_x.data_ptr()), net.detect_resident(0.24, 0.1)), iters),
+    }
+    print("%s %dx%d batch 1 (median of %d calls, ms; second column: forward replayed from a hipGraph):" % (name, size, size, iters))
     for k, v in res.items():
-        print("  %-34s %8.3f" % (k, v))
+        print("  %-34s %8.3f %8.3f" % (k, v, res_g[k]))
 
 
 if __name__ == "__main__":
