@@ -973,7 +973,15 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         const size_t lds = stem_lds_bytes(d);
         const int nt = (d->n + 31) / 32;
         void (*fn)(ConvK) = nt == 1 ? conv_stem_kernel<1> : nt == 2 ? conv_stem_kernel<2> : nt == 3 ? conv_stem_kernel<3> : conv_stem_kernel<4>;
-        Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            static size_t attr_lds[16][4] = {{0}};       // per device and instantiation: largest size requested so far
+            int dev = 0;
+            Y2H_CHECK(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 16 || attr_lds[dev][nt - 1] < lds) {
+                Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (dev >= 0 && dev < 16) attr_lds[dev][nt - 1] = lds;
+            }
+        }
         const long ntiles = ((long)a.npix + 31) / 32;
         int bpc = (int)(160 * 1024 / lds);
         if (bpc > 4) bpc = 4;

@@ -650,7 +650,16 @@ static int c32_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
                                 : (a.pool ? conv_c32_f16_kernel<2, true> : conv_c32_f16_kernel<2, false>);
     const size_t lds = (size_t)2 * 18 * 1664 + 4 * 8 * 144;
     a.vec_store = d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !getenv("Y2_C32_SCALAR");
-    Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        static bool attr_set[16][4] = {{false}};         // per device and instantiation: the attribute call is not free
+        const int which = (nf - 1) * 2 + (a.pool ? 1 : 0);
+        int dev = 0;
+        Y2H_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16 || !attr_set[dev][which]) {
+            Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 16) attr_set[dev][which] = true;
+        }
+    }
     long tiles = (long)d->batch * (d->h >> 4) * (d->w >> 4);
     long grid = tiles < 512 ? tiles : 512;               // two workgroups per CU, tiles are grid-strided
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, S(s), a);
