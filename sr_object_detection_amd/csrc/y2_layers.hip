@@ -491,7 +491,7 @@ extern "C" int y2h_batchnorm(const float *x, int ldx, float *y, int ldy, long pi
 // used once per image, so the layer streams its weights from HBM (yolov1/yolo.cfg: 49 x 256 x 9216 floats = 462 MB):
 // one wave owns (location, 4 filters), lanes stride over the K = size*size*c taps with 16-byte loads of the weights
 // (re-ordered at upload to [location][filter][kh][kw][c], matching the NHWC activations) and of the input, up to
-// four images per pass so the weights are read once per four images; a wave reduction finishes the dot products.
+// eight images per pass so the weights are read once per eight images; a wave reduction finishes the dot products.
 //   y = act(bias + sum_k w*x)         (the reference adds the bias first; same value to rounding)
 // local_ref_kernel is the strict-mode form: one thread per output value, bias first, taps in the reference's
 // k = (c, kh, kw) order, product and sum rounded separately -- the arithmetic of gemm_nn (gemm.c:74-88).
@@ -676,9 +676,12 @@ extern "C" int y2h_local(const float *x, int ldx, const float *w_packed, const f
     if (batch == 1) {
         if (vec) hipLaunchKernelGGL((local_kernel<1, true>), dim3(blocks), dim3(256), 0, S(s), a);
         else hipLaunchKernelGGL((local_kernel<1, false>), dim3(blocks), dim3(256), 0, S(s), a);
-    } else {
+    } else if (batch <= 4) {
         if (vec) hipLaunchKernelGGL((local_kernel<4, true>), dim3(blocks), dim3(256), 0, S(s), a);
         else hipLaunchKernelGGL((local_kernel<4, false>), dim3(blocks), dim3(256), 0, S(s), a);
+    } else {        // eight images per pass over the weights
+        if (vec) hipLaunchKernelGGL((local_kernel<8, true>), dim3(blocks), dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL((local_kernel<8, false>), dim3(blocks), dim3(256), 0, S(s), a);
     }
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;

@@ -95,10 +95,10 @@ def test_every_layer_of_mini_v1_against_oracle(oracle, workdir, name):
     on.close()
 
 
-@pytest.mark.parametrize("batch", [1, 3, 5])
+@pytest.mark.parametrize("batch", [1, 3, 5, 8, 11])
 def test_local_layer_batches_and_unaligned_channels(oracle, workdir, batch):
     """[local] with c % 4 != 0 (scalar tap loads), a filter count that is not a multiple of 4, stride 2, and batches on
-    either side of the four-images-per-pass blocking."""
+    either side of the four- and eight-images-per-pass blockings."""
     from sr_object_detection_amd import synth, zoo
     import os
     spec = [("conv", 6, 3, 1, "leaky"), ("local", 7, 3, 2, 1, "leaky"), ("local", 5, 2, 1, 0, "relu"), ("connected", 36, 0, "linear"),
