@@ -11,6 +11,9 @@
 //  * conv_first_kernel -- the 3-channel first layer (K = 27): no LDS, haloed input, 14 MFMAs per 32
 //    pixels, optional fused 2x2 maxpool; HBM bound.
 //
+//  * conv_stem_kernel -- few-channel first layers of any size / stride (7x7/2, 11x11/4, ...): same shape, with the
+//    weights and tap offsets in LDS.
+//
 //  * splitk_reduce_kernel -- second pass of layers whose K loop was cut across workgroups.
 //
 //  * conv_mfma_kernel -- implicit GEMM on the fp32 matrix cores
@@ -32,8 +35,11 @@
 //    CPU path (separately rounded mul+add, ci-major k order) only by ordinary
 //    fp32 summation noise (~1e-6 relative).
 //
-//  * conv_direct_kernel -- plain VALU kernel for shapes the MFMA kernel does
-//    not take (Cin=3 first layer, odd strides/sizes) and for the strict mode:
+//    Strides are free (the GEMM rows enumerate the output grid; taps are centred on input (oy*s, ox*s)); sizes 1, 3
+//    and 5 are instantiated (one tap-validity mask bit per tap, pad = size/2).
+//
+//  * conv_direct_kernel -- plain VALU kernel for shapes the MFMA kernels do
+//    not take (Cin not a multiple of 16 behind the first layer, even sizes) and for the strict mode:
 //    it accumulates in the reference's exact order (ci, kh, kw ascending;
 //    product and sum rounded separately, gemm.c:74-88) and is bit-identical to
 //    the CPU path.
