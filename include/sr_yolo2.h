@@ -221,6 +221,11 @@ int y2_validate_detector_frames(network net, float *frames, int n, char **paths,
  * progress line per frame on stderr and returns the running totals. */
 typedef struct { int total, correct, proposals; float avg_iou; } y2_recall;
 int y2_validate_recall_frames(network net, float *frames, int n, const box *truth, const int *truth_first, y2_recall *res);
+/* validate_classifier_single (classifier.c:469-529) over `n` network-sized CHW frames in memory: truth[f] is the class
+ * the reference derives from the file path (-1 = none); per frame network_predict -> top_k -> running top-1 / top-k
+ * accuracy, the reference's progress line on stdout; the final averages are returned.  Returns 0 / -1. */
+int y2_validate_classifier_frames(network net, float *frames, int n, const int *truth, int classes, int topk,
+                                  float *top1_out, float *topk_out);
 
 /* ---- small helpers the callers use (option_list.h:12-19, data.c:474, utils.c, tree.c, image.c) ---- */
 list *read_data_cfg(char *filename);

@@ -231,3 +231,40 @@ done:
     free(staging);
     return rc;
 }
+
+/* validate_classifier_single (classifier.c:469-529) with the image list replaced by `n` network-sized CHW frames in
+ * memory and the label-from-path lookup (:502-507) by `truth[f]` (-1 = no label, as when no label string matches):
+ * per frame network_predict -> top_k(pred, classes, topk, indexes) -> running top-1 / top-k accuracy, the reference's
+ * progress line per frame on stdout.  Frames are processed net.batch at a time.  A hierarchical classifier
+ * (net.hierarchy, softmax tree=) is refused: that head is not implemented on the device. */
+int y2_validate_classifier_frames(network net, float *frames, int n, const int *truth, int classes, int topk,
+                                  float *top1_out, float *topk_out)
+{
+    float *staging = NULL, avg_acc = 0, avg_topk = 0;
+    int *indexes = NULL, i, b, j, rc = -1, outputs;
+    if (!frames || n <= 0 || !truth || classes <= 0 || topk <= 0) { y2_fail("y2_validate_classifier_frames: missing argument"); return -1; }
+    if (net.hierarchy) { y2_fail("y2_validate_classifier_frames: hierarchical classifiers (softmax tree=) are not implemented on the device"); return -1; }
+    outputs = get_network_output_size(net);
+    if (classes > outputs || topk > classes) { y2_fail("y2_validate_classifier_frames: classes %d / top %d against %d network outputs", classes, topk, outputs); return -1; }
+    indexes = calloc(topk, sizeof(int));
+    staging = calloc((size_t)net.inputs * net.batch, sizeof(float));
+    if (!indexes || !staging) { y2_fail("out of memory"); goto done; }
+    for (i = 0; i < n; i += net.batch) {
+        float *out = predict_chunk(net, frames, i, n, staging);
+        if (!out) goto done;
+        for (b = 0; b < net.batch && i + b < n; ++b) {
+            const int f = i + b;
+            top_k(out + (size_t)b * outputs, classes, topk, indexes);
+            if (indexes[0] == truth[f]) avg_acc += 1;
+            for (j = 0; j < topk; ++j) if (indexes[j] == truth[f]) avg_topk += 1;
+            printf("%d: top 1: %f, top %d: %f\n", f, avg_acc / (f + 1), topk, avg_topk / (f + 1));
+        }
+    }
+    if (top1_out) *top1_out = avg_acc / n;
+    if (topk_out) *topk_out = avg_topk / n;
+    rc = 0;
+done:
+    free(indexes);
+    free(staging);
+    return rc;
+}

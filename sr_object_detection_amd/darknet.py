@@ -498,6 +498,19 @@ class Network:
             raise Y2Error("y2_validate_recall_frames: " + _check())
         return dict(total=res.total, correct=res.correct, proposals=res.proposals, avg_iou=res.avg_iou)
 
+    def validate_classifier_frames(self, frames: np.ndarray, truth, classes: int, topk: int):
+        """validate_classifier_single (classifier.c:469) over in-memory frames -> (top-1 accuracy, top-k accuracy)."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        truth = np.ascontiguousarray(truth, dtype=np.int32)
+        a, b = C.c_float(), C.c_float()
+        L = lib()
+        L.y2_validate_classifier_frames.argtypes = [CNetwork, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        if L.y2_validate_classifier_frames(self.net, _ptr(frames), frames.shape[0], _ptr(truth), classes, topk,
+                                           C.byref(a), C.byref(b)) != 0:
+            raise Y2Error("y2_validate_classifier_frames: " + _check())
+        return a.value, b.value
+
     def pull_layer_output(self, i: int) -> np.ndarray:
         l = self.net.layers[i]
         out = np.zeros(self.net.batch * l.outputs, dtype=np.float32)

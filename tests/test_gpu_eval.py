@@ -124,3 +124,32 @@ def test_validate_recall_frames_matches_oracle(oracle, workdir):
     assert got["correct"] > 0 and got["total"] > got["correct"]
     assert abs(got["avg_iou"] - float(want["avg_iou"])) < 1e-5
     net.free()
+
+
+def test_validate_classifier_frames_counts_like_the_reference_loop(oracle, workdir):
+    """y2_validate_classifier_frames (classifier.c:469-529 over in-memory frames): top-1 / top-k running accuracy against
+    labels, batch chunks with a ragged tail, equal to the same loop over the oracle's predictions"""
+    import os
+    from sr_object_detection_amd import synth, zoo
+    cfg = os.path.join(workdir, "cls.cfg")
+    open(cfg, "w").write(zoo.cfg_text("darknet-ref", 64, 64, 4))
+    wts = os.path.join(workdir, "cls.weights")
+    synth.write_weights(wts, zoo.resolve("darknet-ref", 64), 3, 1.0)
+    n, classes, topk = 10, 1000, 5
+    frames = synth.image_batch(n, 3, 64, 64, seed=40)
+    on = oracle.OracleNet(cfg, wts)
+    preds = np.concatenate([on.predict(np.concatenate([frames[i:i + 4], np.zeros((4 - len(frames[i:i + 4]), 3, 64, 64), np.float32)]))
+                            .reshape(4, -1)[:len(frames[i:i + 4])] for i in range(0, n, 4)])
+    order = np.argsort(-preds, axis=1, kind="stable")
+    # labels: the true top-1 for some frames, the third-best for others, a wrong class, and "no label"
+    truth = np.array([order[f, 0] if f % 4 == 0 else order[f, 2] if f % 4 == 1 else order[f, 50] if f % 4 == 2 else -1 for f in range(n)], np.int32)
+    gaps = np.sort(preds, axis=1)[:, ::-1]
+    assert (gaps[:, :6] - gaps[:, 1:7]).min() > 1e-6            # the top of every ranking is well separated
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    top1, top5 = net.validate_classifier_frames(frames, truth, classes, topk)
+    want1 = np.mean([order[f, 0] == truth[f] for f in range(n)])
+    want5 = np.mean([truth[f] in order[f, :topk] for f in range(n)])
+    assert abs(top1 - want1) < 1e-6 and abs(top5 - want5) < 1e-6 and want1 == 0.3 and want5 == 0.6
+    net.free()
+    on.close()
