@@ -208,12 +208,15 @@ int get_coco_image_id(char *filename);                                          
 void print_cocos(FILE *fp, char *image_path, box *boxes, float **probs, int num_boxes, int classes, int w, int h);
 void print_detector_detections(FILE **fps, char *id, box *boxes, float **probs, int total, int classes, int w, int h);
 void print_imagenet_detections(FILE *fp, int id, box *boxes, float **probs, int total, int classes, int w, int h);
+void print_yolo_detections(FILE **fps, char *id, box *boxes, float **probs, int total, int classes, int w, int h);   /* yolo.c:95 */
 char *basecfg(char *cfgfile);                                                             /* utils.c:121 */
 /* validate_detector (detector.c:245-368) with the image list replaced by `n` network-sized CHW frames in
  * memory: per frame network_predict -> get_region_boxes(l, orig_w, orig_h, .005, .., 0, map) ->
  * do_nms_sort(.45) -> the writer `eval` selects: "voc" (default; <prefix>/comp4_det_test_<name>.txt per
  * class, id = basecfg(path)), "coco" (<prefix>/coco_results.json), "imagenet" (200 classes,
- * <prefix>/imagenet-detection.txt).  Frames are processed net.batch at a time.  Returns 0 / -1. */
+ * <prefix>/imagenet-detection.txt).  A network ending in [detection] (YOLOv1) follows validate_yolo (yolo.c:116-200)
+ * instead: get_detection_boxes at .001, do_nms_sort(.5), print_yolo_detections (voc files only).
+ * Frames are processed net.batch at a time.  Returns 0 / -1. */
 int y2_validate_detector_frames(network net, float *frames, int n, char **paths, int *orig_w, int *orig_h,
                                 char *eval, char *prefix, char **names, int *map);
 /* validate_detector_recall (detector.c:371-450): thresh .2, objectness-only decode, do_nms(.., 1, .4), IoU .5

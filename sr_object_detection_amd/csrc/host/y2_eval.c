@@ -115,6 +115,24 @@ static float *predict_chunk(network net, float *frames, int first, int n, float 
     return network_predict(net, staging);
 }
 
+/* yolo.c:95-114: the YOLOv1 writer -- corner form clipped to [0,w] x [0,h] (no +1 offset), one file per class */
+void print_yolo_detections(FILE **fps, char *id, box *boxes, float **probs, int total, int classes, int w, int h)
+{
+    int i, j;
+    for (i = 0; i < total; ++i) {
+        float xmin = boxes[i].x - boxes[i].w / 2.;
+        float xmax = boxes[i].x + boxes[i].w / 2.;
+        float ymin = boxes[i].y - boxes[i].h / 2.;
+        float ymax = boxes[i].y + boxes[i].h / 2.;
+        if (xmin < 0) xmin = 0;
+        if (ymin < 0) ymin = 0;
+        if (xmax > w) xmax = w;
+        if (ymax > h) ymax = h;
+        for (j = 0; j < classes; ++j)
+            if (probs[i][j]) fprintf(fps[j], "%s %f %f %f %f %f\n", id, probs[i][j], xmin, ymin, xmax, ymax);
+    }
+}
+
 int y2_validate_detector_frames(network net, float *frames, int n, char **paths, int *orig_w, int *orig_h,
                                 char *eval, char *prefix, char **names, int *map)
 {
@@ -124,13 +142,17 @@ int y2_validate_detector_frames(network net, float *frames, int n, char **paths,
     FILE *fp = NULL, **fps = NULL;
     det_arrays d = {0};
     float *staging = NULL;
-    const float thresh = .005f, nms = .45f;       /* detector.c:305-306 */
+    /* a network ending in [detection] (YOLOv1) follows validate_yolo instead (yolo.c:116-200): thresh .001, NMS .5,
+     * get_detection_boxes, print_yolo_detections */
+    const int v1 = net.n > 0 && net.layers[net.n - 1].type == DETECTION;
+    const float thresh = v1 ? .001f : .005f, nms = v1 ? .5f : .45f;       /* detector.c:305-306 / yolo.c:150-152 */
     const char *base = "comp4_det_test_";
     if (!frames || n <= 0 || !paths || !orig_w || !orig_h || !prefix) { y2_fail("y2_validate_detector_frames: missing argument"); return -1; }
-    if (net.n <= 0 || net.layers[net.n - 1].type != REGION) { y2_fail("y2_validate_detector_frames: the network does not end in a region layer"); return -1; }
+    if (net.n <= 0 || (net.layers[net.n - 1].type != REGION && !v1)) { y2_fail("y2_validate_detector_frames: the network does not end in a region or detection layer"); return -1; }
+    if (v1 && eval && (0 == strcmp(eval, "coco") || 0 == strcmp(eval, "imagenet"))) { y2_fail("y2_validate_detector_frames: a [detection] head writes the voc format only"); return -1; }
     l = net.layers[net.n - 1];
     classes = l.classes;
-    total = l.w * l.h * l.n;
+    total = v1 ? l.side * l.side * l.n : l.w * l.h * l.n;
     if (eval && 0 == strcmp(eval, "coco")) {
         snprintf(buff, sizeof buff, "%s/coco_results.json", prefix);
         fp = fopen(buff, "w");
@@ -162,11 +184,13 @@ int y2_validate_detector_frames(network net, float *frames, int n, char **paths,
             layer lb = l;
             const int w = orig_w[i + b], h = orig_h[i + b];
             lb.output = out + (size_t)b * l.outputs;                 /* this frame's slice of the region output */
-            get_region_boxes(lb, w, h, thresh, d.probs, d.boxes, 0, map);
+            if (v1) get_detection_boxes(lb, w, h, thresh, d.probs, d.boxes, 0);
+            else get_region_boxes(lb, w, h, thresh, d.probs, d.boxes, 0, map);
             if (y2_failed()) goto done;
             if (nms) do_nms_sort(d.boxes, d.probs, total, classes, nms);
             if (y2_failed()) goto done;
-            if (coco) print_cocos(fp, paths[i + b], d.boxes, d.probs, total, classes, w, h);
+            if (v1) { char *id = basecfg(paths[i + b]); print_yolo_detections(fps, id, d.boxes, d.probs, total, classes, w, h); free(id); }
+            else if (coco) print_cocos(fp, paths[i + b], d.boxes, d.probs, total, classes, w, h);
             else if (imagenet) print_imagenet_detections(fp, i + b + 1, d.boxes, d.probs, total, classes, w, h);
             else { char *id = basecfg(paths[i + b]); print_detector_detections(fps, id, d.boxes, d.probs, total, classes, w, h); free(id); }
         }

@@ -153,3 +153,49 @@ def test_validate_classifier_frames_counts_like_the_reference_loop(oracle, workd
     assert abs(top1 - want1) < 1e-6 and abs(top5 - want5) < 1e-6 and want1 == 0.3 and want5 == 0.6
     net.free()
     on.close()
+
+
+def test_validate_detector_frames_yolov1_follows_validate_yolo(oracle, workdir, tmp_path):
+    """a network ending in [detection]: yolo.c:116-200 validate_yolo -- get_detection_boxes at .001, do_nms_sort(.5),
+    print_yolo_detections (corner boxes clipped to [0,w] x [0,h], no +1) -- byte for byte in strict mode"""
+    g = load_golden("mini_v1_32_b2")
+    seed, gain = int(g["seed"]), float(g["head_gain"])
+    cfg1, wts, _ = materialize(workdir, "mini-v1", 32, 1, seed, gain)
+    cfgb, _, _ = materialize(workdir, "mini-v1", 32, 2, seed, gain)
+    n = 3
+    frames = synth.image_batch(n, 3, 32, 32, seed=777)
+    ow, oh = np.array([500, 353, 32], np.int32), np.array([375, 500, 32], np.int32)
+    paths = ["/data/VOC/JPEGImages/%06d.jpg" % i for i in range(n)]
+    net = darknet.Network.parse_network_cfg(cfgb)
+    net.load_weights(wts)
+    classes = net.last.classes
+    names = ["cls%d" % j for j in range(classes)]
+    want = {nm: [] for nm in names}
+    on = oracle.OracleNet(cfg1, wts)
+    for f in range(n):
+        on.predict(frames[f:f + 1])
+        boxes, probs = on.detection_boxes(0, 0.001, w=int(ow[f]), h=int(oh[f]))
+        post = oracle.do_nms_sort(boxes, probs, 0.5)
+        for i in range(len(boxes)):
+            x, y, w, h = (np.float64(v) for v in boxes[i])
+            xmin, xmax = np.float32(x - w / 2.0), np.float32(x + w / 2.0)
+            ymin, ymax = np.float32(y - h / 2.0), np.float32(y + h / 2.0)
+            xmin, ymin = max(xmin, np.float32(0)), max(ymin, np.float32(0))
+            xmax, ymax = min(xmax, np.float32(ow[f])), min(ymax, np.float32(oh[f]))
+            for j in range(classes):
+                if post[i, j]:
+                    want[names[j]].append("%06d %f %f %f %f %f\n" % (f, post[i, j], xmin, ymin, xmax, ymax))
+    on.close()
+    net.set_strict(True)
+    out = str(tmp_path / "v1")
+    os.makedirs(out)
+    net.validate_detector_frames(frames, paths, ow, oh, out, "voc", names)
+    lines = 0
+    for nm in names:
+        got = open(os.path.join(out, "comp4_det_test_%s.txt" % nm)).read()
+        assert got == "".join(want[nm]), nm
+        lines += len(want[nm])
+    assert lines > 10
+    with pytest.raises(darknet.Y2Error):
+        net.validate_detector_frames(frames, paths, ow, oh, out, "coco")
+    net.free()
