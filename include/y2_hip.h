@@ -189,6 +189,8 @@ int y2h_batchnorm(const float *x, int ldx, float *y, int ldy, long pixels, int c
 int y2h_local(const float *x, int ldx, const float *w_packed, const float *bias_packed, float *y, int ldy, int batch,
               int h, int w, int c, int n, int size, int stride, int pad, int out_h, int out_w, int activation,
               int strict, y2h_stream s);
+/* binarize_cpu (convolutional_layer.c:52-58) for xnor=1 convolutions: y[row][k] = x[row*ldx + k] > 0 ? 1 : -1, y contiguous */
+int y2h_binarize(const float *x, int ldx, float *y, long rows, int c, y2h_stream s);
 /* activate_array (activations.c:95-101, the formulas of activations.h:21-54) in place on channels 0..c-1 of `rows`
  * pixels with channel stride ld; any Y2H_ACT_* code */
 int y2h_activate_array(float *x, int ld, long rows, int c, int activation, y2h_stream s);

@@ -56,6 +56,7 @@ typedef struct {
     int classes, coords, softmax, classfix;
     int side, sqrt_;   /* [detection] */
     int noadjust;      /* [crop] */
+    int xnor;          /* [convolutional] xnor=1 */
     int groups;
     float temperature;
     int dontload, dontloadscales;
@@ -286,7 +287,8 @@ orc_net *orc_parse_cfg(const char *path)
             l->activation = activation_from_name(opt(s, "activation") ? opt(s, "activation") : "logistic");
             l->batch_normalize = opt_int(s, "batch_normalize", 0);
             l->flipped = opt_int(s, "flipped", 0);
-            if (opt_int(s, "binary", 0) || opt_int(s, "xnor", 0)) { fprintf(stderr, "oracle: binary/xnor conv out of scope\n"); return NULL; }
+            if (opt_int(s, "binary", 0)) { fprintf(stderr, "oracle: binary=1 convolutions are out of scope (the reference's CPU path corrupts their weights)\n"); return NULL; }
+            l->xnor = opt_int(s, "xnor", 0);
             if (!(h && w && c)) { fprintf(stderr, "Layer before convolutional layer must output image.\n"); return NULL; }
             l->h = h; l->w = w; l->c = c;
             l->out_h = (h + 2 * l->pad - l->size) / l->stride + 1;
@@ -665,11 +667,30 @@ static void forward_conv(orc_net *net, orc_layer *l, const float *input)
 {
     int m = l->n, k = l->size * l->size * l->c, n = l->out_h * l->out_w, b, f;
     size_t total = (size_t)l->outputs * l->batch, t;
+    const float *wts = l->weights;
+    float *bw = NULL, *bin = NULL;
     memset(l->output, 0, total * sizeof(float));
+    if (l->xnor) {
+        /* convolutional_layer.c:443-447: binarize_weights (:37-50: per filter +-mean|w|, the mean a sequential fp32 sum of
+         * double fabs values), binarize_cpu on the input (:52-58: +-1) */
+        size_t e, ni = (size_t)l->c * l->h * l->w * l->batch;
+        bw = malloc((size_t)m * k * sizeof(float));
+        bin = malloc(ni * sizeof(float));
+        for (f = 0; f < m; ++f) {
+            float mean = 0;
+            int i;
+            for (i = 0; i < k; ++i) mean += fabs(l->weights[(size_t)f * k + i]);
+            mean = mean / k;
+            for (i = 0; i < k; ++i) bw[(size_t)f * k + i] = (l->weights[(size_t)f * k + i] > 0) ? mean : -mean;
+        }
+        for (e = 0; e < ni; ++e) bin[e] = (input[e] > 0) ? 1 : -1;
+        wts = bw; input = bin;
+    }
     for (b = 0; b < l->batch; ++b) {
         im2col(input + (size_t)b * l->c * l->h * l->w, l->c, l->h, l->w, l->size, l->stride, l->pad, net->workspace);
-        gemm_rows(m, n, k, l->weights, k, net->workspace, n, l->output + (size_t)b * n * m, n);
+        gemm_rows(m, n, k, wts, k, net->workspace, n, l->output + (size_t)b * n * m, n);
     }
+    free(bw); free(bin);
     if (l->batch_normalize) {
 #pragma omp parallel for collapse(2)
         for (b = 0; b < l->batch; ++b) for (f = 0; f < m; ++f) {

@@ -369,7 +369,10 @@ static layer make_conv(list *o, shape p)
     l.xnor = option_find_int_quiet(o, "xnor", 0);
     l.flipped = option_find_int_quiet(o, "flipped", 0);
     option_find(o, "dot");
-    if (l.binary || l.xnor) { y2_fail("binary/xnor convolution is outside the supported forward path"); return l; }
+    /* binary=1: the reference's CPU forward swaps the binarized copy in only at the END of the layer
+     * (convolutional_layer.c:473), i.e. it convolves with the real weights once and with zeros afterwards -- nothing to
+     * be compatible with.  xnor=1 (binarized weights and input, :443-447) is implemented. */
+    if (l.binary) { y2_fail("binary=1 convolutions are not supported (the reference's CPU path corrupts their weights after the first call)"); return l; }
     if (!(p.h && p.w && p.c)) { y2_fail("Layer before convolutional layer must output image."); return l; }
     if (l.n <= 0 || l.size <= 0 || l.stride <= 0) { y2_fail("bad convolutional geometry"); return l; }
     l.batch = p.batch; l.h = p.h; l.w = p.w; l.c = p.c;

@@ -95,6 +95,7 @@ static void free_plan(network *net)
         y2h_free(d->d_region); d->d_region = NULL;
         y2h_free(d->d_flat); d->d_flat = NULL;
         y2h_free(d->d_halo); d->d_halo = NULL; d->halo_px = 0;
+        y2h_free(d->d_bin); d->d_bin = NULL;
         d->placed_in = -1; d->alias_of = -1; d->copy_mask = 0;
         d->fused_pool = 0; d->fused_into = -1;
         d->out_half = 0;
@@ -199,6 +200,7 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     c->x = x;
     c->x_halo = (i == 0 && e->in_halo) ? e->in_halo_px : 0;   /* in_halo 2: half [b][h+2][w+2][4] for the fp16 first-layer kernel */
     if (i > 0 && ld_of(&net->layers[i - 1])->d_halo) c->x_halo = ld_of(&net->layers[i - 1])->halo_px;
+    if (l->xnor) c->x_halo = 0;
     c->fuse_maxpool2 = d->fused_pool;
     c->ws = e->d_ws;
     c->ws_bytes = e->ws_bytes;
@@ -229,6 +231,10 @@ static void input_view(const network *net, int i, const float **x, int *ldx)
         const y2_ldev *p = ld_of(&net->layers[i - 1]);
         *x = p->out; *ldx = p->out_ld;
         if (p->d_halo && net->layers[i].type == CONVOLUTIONAL) { *x = p->d_halo; *ldx = net->layers[i - 1].out_c; }
+    }
+    /* an xnor convolution reads the binarized copy of its input */
+    if (net->layers[i].type == CONVOLUTIONAL && net->layers[i].xnor && ld_of(&net->layers[i])->d_bin) {
+        *x = ld_of(&net->layers[i])->d_bin; *ldx = net->layers[i].c;
     }
     /* a [connected] layer is run as a 1x1 convolution over a 1x1 image whose channels are the whole input vector */
     if (net->layers[i].type == CONNECTED) *ldx = net->layers[i].inputs;
@@ -340,15 +346,23 @@ static int upload_weights(network *net)
                         wp[(size_t)co * K + (size_t)pix * C + ci] = l->weights[(size_t)co * K + (size_t)ci * hw + pix];
         } else
         /* reference layout [n][c][kh][kw] (im2col.c:24-27) -> kernel layout [n][kh][kw][c] */
-        for (co = 0; co < l->n; ++co)
+        for (co = 0; co < l->n; ++co) {
+            float bmean = 0;
+            if (l->xnor) {          /* binarize_weights, convolutional_layer.c:37-50: +-mean|w| per filter, sequential fp32 sum */
+                int q;
+                for (q = 0; q < K; ++q) bmean += fabs(l->weights[(size_t)co * K + q]);
+                bmean = bmean / K;
+            }
             for (ci = 0; ci < l->c; ++ci)
                 for (kh = 0; kh < l->size; ++kh)
                     for (kw = 0; kw < l->size; ++kw) {
                         const size_t dst = (size_t)co * K + (size_t)(kh * l->size + kw) * l->c + ci;
-                        const float v = l->weights[(((size_t)co * l->c + ci) * l->size + kh) * l->size + kw];
+                        float v = l->weights[(((size_t)co * l->c + ci) * l->size + kh) * l->size + kw];
+                        if (l->xnor) v = (v > 0) ? bmean : -bmean;
                         if (w_half) ((unsigned short *)wp)[dst] = f32_to_f16_rne(v);
                         else wp[dst] = v;
                     }
+        }
         if (w_half) {
             /* folded batch-norm for the fp16 kernels: y = act(acc*alpha + beta), constants evaluated in double */
             float *al = (float *)(host + d->off_alpha), *be = (float *)(host + d->off_beta);
@@ -362,6 +376,16 @@ static int upload_weights(network *net)
             }
         }
         if (d->has_w_ref) memcpy(host + d->off_w_ref, l->weights, (size_t)l->n * K * sizeof(float));
+        if (d->has_w_ref && l->type == CONVOLUTIONAL && l->xnor) {
+            float *wr = (float *)(host + d->off_w_ref);
+            for (co = 0; co < l->n; ++co) {
+                float bmean = 0;
+                int q;
+                for (q = 0; q < K; ++q) bmean += fabs(l->weights[(size_t)co * K + q]);
+                bmean = bmean / K;
+                for (q = 0; q < K; ++q) wr[(size_t)co * K + q] = (l->weights[(size_t)co * K + q] > 0) ? bmean : -bmean;
+            }
+        }
         b = (float *)(host + d->off_bias);
         memcpy(b, l->biases, l->n * sizeof(float));
         if (l->batch_normalize) {
@@ -450,6 +474,7 @@ int y2_engine_build(network *net)
             y2_ldev *d = ld_of(l), *pd = i > 0 ? ld_of(&net->layers[i - 1]) : NULL;
             switch (l->type) {
             case CONVOLUTIONAL:
+                if (l->xnor) { y2_fail("fp16 mode: layer %d: xnor convolutions have no half-precision form", i); return -1; }
                 if (!act_in_kernel(l->activation)) { y2_fail("fp16 mode: layer %d: activation %d has no half-precision form", i, (int)l->activation); return -1; }
                 /* the conv feeding a region head writes fp32: the head's logistic/softmax/exp run in fp32 */
                 d->out_half = !(i + 1 < net->n && net->layers[i + 1].type == REGION);
@@ -577,7 +602,7 @@ int y2_engine_build(network *net)
             y2_ldev *d = ld_of(l);
             y2h_conv c0;
             int px;
-            if (l->type != CROP || nl->type != CONVOLUTIONAL || nl->c > 4 || ld_of(nl)->fused_pool) continue;
+            if (l->type != CROP || nl->type != CONVOLUTIONAL || nl->c > 4 || ld_of(nl)->fused_pool || nl->xnor) continue;
             memset(&c0, 0, sizeof c0);
             c0.batch = nl->batch; c0.h = nl->h; c0.w = nl->w; c0.c = nl->c; c0.ldx = nl->c; c0.n = nl->n;
             c0.size = nl->size; c0.stride = nl->stride; c0.pad = nl->pad; c0.out_h = nl->out_h; c0.out_w = nl->out_w;
@@ -592,10 +617,16 @@ int y2_engine_build(network *net)
             }
         }
     }
+    /* xnor=1 convolutions (convolutional_layer.c:443-447) read a +-1 copy of their input */
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        if (l->type == CONVOLUTIONAL && l->xnor)
+            HIPCALL(y2h_malloc((void **)&ld_of(l)->d_bin, (size_t)l->batch * l->h * l->w * l->c * sizeof(float)));
+    }
     /* io */
     e->in_floats = (size_t)net->batch * net->inputs;
     e->in_halo = 0;
-    if (!e->strict && net->n > 0 && net->layers[0].type == CONVOLUTIONAL) {
+    if (!e->strict && net->n > 0 && net->layers[0].type == CONVOLUTIONAL && !net->layers[0].xnor) {
         /* a 3-channel 3x3 first layer reads its input with a one-pixel zero halo (no tap bounds tests) */
         const layer *l0 = &net->layers[0];
         y2h_conv c0;
@@ -842,6 +873,13 @@ static int enqueue_forward(network *net, const float *d_input_nchw)
         switch (l->type) {
         case CONVOLUTIONAL: {
             y2h_conv c;
+            if (l->xnor) {
+                /* input_view already points at d_bin: binarize the producer's activations into it first */
+                const float *px; int pld;
+                if (i == 0) { px = e->d_in_nhwc; pld = net->c; }
+                else { const y2_ldev *p = ld_of(&net->layers[i - 1]); px = p->out; pld = p->out_ld; }
+                HIPCALL(y2h_binarize(px, pld, d->d_bin, (long)l->batch * l->h * l->w, l->c, e->stream));
+            }
             conv_desc(net, i, &c, x, ldx);
             HIPCALL(y2h_conv_forward(&c, e->strict, e->stream));
             if (!act_in_kernel(l->activation))

@@ -40,6 +40,7 @@ typedef struct y2_ldev {
      * pixels ([batch][out_h+2p][out_w+2p][out_c]), which is what the first-layer / stem kernels read */
     float *d_halo;
     int halo_px;
+    float *d_bin;              /* xnor=1 convolution: its input binarized to +-1 ([batch][h][w][c], contiguous) */
     const char *kernel;        /* name for profiles */
 } y2_ldev;
 

@@ -530,6 +530,24 @@ __device__ float activate_any(float x, int act)
     return x;
 }
 
+// binarize_cpu (convolutional_layer.c:52-58): +1 where the value is positive, -1 elsewhere; NHWC in, contiguous NHWC out
+__global__ __launch_bounds__(256) void binarize_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y, int c, long total)
+{
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / c;
+        y[idx] = (x[row * ldx + (idx - row * c)] > 0) ? 1.f : -1.f;
+    }
+}
+
+extern "C" int y2h_binarize(const float *x, int ldx, float *y, long rows, int c, y2h_stream s)
+{
+    if (!x || !y || rows <= 0 || c <= 0 || ldx < c) return Y2H_EINVAL;
+    const long total = rows * c;
+    hipLaunchKernelGGL(binarize_kernel, dim3(y2h_grid(total, 256)), dim3(256), 0, S(s), x, ldx, y, c, total);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
 __global__ __launch_bounds__(256) void activate_kernel(float *__restrict__ x, int ld, int c, int act, long total)
 {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {

@@ -15,7 +15,7 @@ synthetic weights and to report FLOPs; the engine does its own parse in C.
 from __future__ import annotations
 
 # spec entries:
-#   ("conv", filters, size, bn, activation[, stride[, pad flag]])      default stride 1, pad=1 (= size/2 pixels)
+#   ("conv", filters, size, bn, activation[, stride[, pad flag[, xnor]]])      default stride 1, pad=1 (= size/2 pixels)
 #   ("max", size, stride[, padding]) | ("route", [idx...]) | ("reorg", stride)
 #   ("region", dict) | ("avg",) | ("softmax",) | ("cost",)
 #   ("crop", width, height, noadjust) | ("batchnorm",) | ("local", filters, size, stride, pad, activation)
@@ -180,6 +180,14 @@ SPECS["yolo-v1-small"] = [("crop", 448, 448, 0)] + [(e[0], e[1], e[2], 0) + tupl
     ("connected", 512, 0, "leaky"), ("connected", 4096, 0, "leaky"), ("dropout", 0.5), ("connected", 1470, 0, "linear"),
     ("detection", {"classes": 20, "num": 2, "side": 7, "softmax": 0, "sqrt": 1})]
 
+# cfg/yolov1/xyolo.test.cfg in small: xnor=1 convolutions (binarized weights and inputs, convolutional_layer.c:443-447)
+# behind standalone [batchnorm] layers
+SPECS["mini-xnor"] = [
+    ("conv", 16, 3, 1, "leaky"), ("max", 2, 2), ("batchnorm",), ("conv", 32, 3, 1, "leaky", 1, 1, 1), ("max", 2, 2), ("batchnorm",),
+    ("conv", 64, 3, 1, "leaky", 1, 1, 1), ("batchnorm",), ("conv", 32, 1, 1, "leaky", 1, 1, 1), ("conv", 30, 1, 0, "linear"),
+    ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]}),
+]
+
 # every activation of activations.h:21-54 outside the four the target cfgs use (strided.cfg is all `ramp`): on
 # matrix-core convolutions, a strided one, a shortcut, and behind a placed (zero-copy) route source
 SPECS["mini-acts"] = [
@@ -203,7 +211,7 @@ SPECS["yolo-v1"] = [
     ("detection", {"classes": 20, "num": 3, "side": 7, "softmax": 0, "sqrt": 1}),
 ]
 
-DEFAULT_SIZE = {"resnet50": 256, "densenet201": 256, "extraction": 224, "darknet-ref": 224, "tiny": 224, "alexnet": 227, "vgg-16": 256,
+DEFAULT_SIZE = {"mini-xnor": 32, "resnet50": 256, "densenet201": 256, "extraction": 224, "darknet-ref": 224, "tiny": 224, "alexnet": 227, "vgg-16": 256,
                 "strided": 256, "yolo-v1-small": 448, "mini-acts": 32, "yolo-v1": 448, "mini-v1-local": 40, "yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32, "tiny-yolo-v1": 448, "mini-v1": 32}
 
 
@@ -222,6 +230,8 @@ def cfg_text(name: str, width: int | None = None, height: int | None = None, bat
             out += ["[convolutional]", "filters=%d" % filters, "size=%d" % size, "stride=%d" % stride, "pad=%d" % (e[6] if len(e) > 6 else 1)]
             if bn:
                 out.append("batch_normalize=1")
+            if len(e) > 7 and e[7]:
+                out.append("xnor=1")
             out += ["activation=%s" % act, ""]
         elif kind == "max":
             out += ["[maxpool]", "size=%d" % e[1], "stride=%d" % e[2]] + (["padding=%d" % e[3]] if len(e) > 3 else []) + [""]

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _open(workdir):
-    g = load_golden("mini_acts_32_b2")
+def _open(workdir, name="mini_acts_32_b2"):
+    g = load_golden(name)
     cfg, wts, x = materialize(workdir, str(g["net"]), int(g["size"]), int(g["batch"]), int(g["seed"]), float(g["head_gain"]))
     net = darknet.Network.parse_network_cfg(cfg)
     net.load_weights(wts)
@@ -36,8 +36,11 @@ def test_forward_and_detections_match_reference_golden(workdir):
     net.free()
 
 
-def test_every_layer_against_oracle_and_strict_is_bit_identical(oracle, workdir):
-    g, net, x, cfg, wts = _open(workdir)
+@pytest.mark.parametrize("name", ["mini_acts_32_b2", "mini_xnor_32_b2"])
+def test_every_layer_against_oracle_and_strict_is_bit_identical(oracle, workdir, name):
+    """(mini_xnor_32_b2: xnor=1 convolutions -- weights binarized to +-mean|w| per filter at upload, inputs to +-1 by
+    binarize_kernel, convolutional_layer.c:443-447 -- behind standalone [batchnorm] layers, as in cfg/yolov1/xyolo.test.cfg)"""
+    g, net, x, cfg, wts = _open(workdir, name)
     on = oracle.OracleNet(cfg, wts)
     ref = on.predict(x)
     assert np.array_equal(ref, g["out"])
@@ -46,11 +49,20 @@ def test_every_layer_against_oracle_and_strict_is_bit_identical(oracle, workdir)
         net.set_fusion(not strict)
         out = net.network_predict(x)
         for i in range(net.n):
+            if net.layer_kernel(i).endswith("+maxpool2"):
+                continue                                   # checked through the maxpool layer's output
             got, want = net.pull_layer_output(i), on.layer_output(i)
             if strict:
                 assert np.array_equal(got, want), (i, net.layer_kernel(i))
             else:
                 assert np.abs(got - want).max() < TOL * max(1.0, float(np.abs(want).max())), (i, net.layer_kernel(i))
         assert np.array_equal(out, ref) if strict else np.abs(out - ref).max() < TOL
+    if name == "mini_xnor_32_b2":
+        net.set_strict(False)
+        net.network_predict(x)
+        assert sum(net.layer_kernel(i).startswith("conv_mfma_f32") for i in range(net.n)) >= 3
+        net.set_half(True)
+        with pytest.raises(darknet.Y2Error):
+            net.network_predict(x)
     net.free()
     on.close()
