@@ -51,6 +51,7 @@
 //
 // This file is compiled with -ffp-contract=off: no mul+add below may fuse.
 #include "y2_conv_shared.hpp"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------
 // MFMA implicit GEMM
@@ -491,69 +492,15 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
 
     // Software pipeline inside the wave: the 14 MFMAs of tile t+1 are interleaved (in program order -- a wave
     // issues in order) with the epilogue of tile t, whose VALU work is several times the MFMA issue time of a tile;
-    // back to back they left the matrix pipe idle during every epilogue (27 % MFMA-busy, 1.4 TB/s).  Out-of-range
-    // rows and filters are dropped by the buffer range check of the stores, so the interleaved block has no branches.
+    // back to back they left the matrix pipe idle during every epilogue (27 % MFMA-busy, 1.4 TB/s).  The interleave
+    // only exists inside ONE basic block, so the pipelined form is compiled for the case that matters -- batch-norm +
+    // leaky, the four combinations of (fused pool, half output) as compile-time constants -- and out-of-range rows and
+    // filters are dropped by the buffer range check of the stores instead of by branches.
     const size_t ybytes_full = a.pool ? (size_t)(a.npix >> 2) * a.ldy : (size_t)a.npix * a.ldy;
     const unsigned esz = a.y_f16 ? 2u : 4u;
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, (unsigned)(ybytes_full * esz), 0x00020000);
-    auto mfma_tile = [&](const float (&av)[14], f32x16 (&acc)[NT]) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 14; ++t)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bw[j][t], acc[j], 0, 0, 0);
-    };
-    auto put = [&](unsigned long row, int co, float v, bool ok) {
-        const unsigned long off = (row * (unsigned long)a.ldy + (unsigned long)co) * esz;
-        const unsigned o = ok ? (unsigned)off : 0xffffffffu;            // out of range: the store is dropped
-        if (a.y_f16) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), yr, o, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, 0, 0);
-    };
-    auto finish_tile = [&](long tile, const f32x16 (&acc)[NT]) {
-        const long prow = tile * 32 + 4 * lh;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int co = j * 32 + li;
-            if (a.pool) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const long r0 = prow + 8 * g;
-                    float m = epilogue_f32(acc[j][4 * g], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
-#pragma unroll
-                    for (int t = 1; t < 4; ++t) {
-                        const float v = epilogue_f32(acc[j][4 * g + t], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
-                        m = (v > m) ? v : m;
-                    }
-                    put((unsigned long)(r0 >> 2), co, m, co < a.Cout && r0 < a.npix);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long p = prow + (r & 3) + 8 * (r >> 2);
-                    put((unsigned long)p, co, epilogue_f32(acc[j][r], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act),
-                        co < a.Cout && p < a.npix);
-                }
-            }
-        }
-    };
-    auto overlap = [&](const float (&av)[14], f32x16 (&acc_next)[NT], long tile_prev, const f32x16 (&acc_prev)[NT]) {
-        mfma_tile(av, acc_next);
-        finish_tile(tile_prev, acc_prev);
-#pragma unroll
-        for (int t = 0; t < 14 * NT; ++t) {          // one MFMA, then a share of the epilogue's VALU work and a store
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
-            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-        }
-    };
-
-    if (NT > 1 || ybytes_full * esz >= 4294967000.0 || t_begin >= t_end) {
+    if (NT > 1 || ybytes_full * esz >= 4294967000.0 || t_begin >= t_end || !a.bn || a.act != Y2H_ACT_LEAKY) {
         // (two accumulator sets of NT = 2 would leave one wave per SIMD; outputs beyond the 32-bit buffer range
-        // cannot use the range-checked stores: plain per-tile path)
+        // cannot use the range-checked stores; other epilogues: plain per-tile path)
         float a0[14], a1[14];
         long tile = t_begin;
         if (tile < t_end) load_tile(a0);
@@ -565,24 +512,84 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
         }
         return;
     }
-    float a0[14], a1[14];
-    f32x16 accA[NT], accB[NT];
-    long cur = t_begin;
-    load_tile(a0);
-    if (cur + 1 < t_end) load_tile(a1);
-    mfma_tile(a0, accA);
-    for (;;) {
-        // accA holds tile cur, a1 the inputs of cur + 1
-        if (cur + 1 >= t_end) { finish_tile(cur, accA); break; }
-        if (cur + 2 < t_end) load_tile(a0);
-        overlap(a1, accB, cur, accA);
-        ++cur;
-        // accB holds tile cur, a0 the inputs of cur + 1
-        if (cur + 1 >= t_end) { finish_tile(cur, accB); break; }
-        if (cur + 2 < t_end) load_tile(a1);
-        overlap(a0, accA, cur, accB);
-        ++cur;
-    }
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, (unsigned)(ybytes_full * esz), 0x00020000);
+    auto pipelined = [&](auto POOLC, auto F16C) {
+        constexpr bool POOL = decltype(POOLC)::value, F16 = decltype(F16C)::value;
+        auto mfma_tile = [&](const float (&av)[14], f32x16 (&acc)[NT]) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 14; ++t)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bw[j][t], acc[j], 0, 0, 0);
+        };
+        auto put = [&](unsigned long row, int co, float v, bool ok) {
+            const unsigned long off = (row * (unsigned long)a.ldy + (unsigned long)co) * (F16 ? 2u : 4u);
+            const unsigned o = ok ? (unsigned)off : 0xffffffffu;            // out of range: the store is dropped
+            if (F16) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), yr, o, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, 0, 0);
+        };
+        auto finish_tile = [&](long tile, const f32x16 (&acc)[NT]) {
+            const long prow = tile * 32 + 4 * lh;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = j * 32 + li;
+                if (POOL) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const long r0 = prow + 8 * g;
+                        float m = epilogue_f32(acc[j][4 * g], true, mean[j], rinv[j], scale[j], bias[j], Y2H_ACT_LEAKY);
+#pragma unroll
+                        for (int t = 1; t < 4; ++t) {
+                            const float v = epilogue_f32(acc[j][4 * g + t], true, mean[j], rinv[j], scale[j], bias[j], Y2H_ACT_LEAKY);
+                            m = (v > m) ? v : m;
+                        }
+                        put((unsigned long)(r0 >> 2), co, m, co < a.Cout && r0 < a.npix);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long p = prow + (r & 3) + 8 * (r >> 2);
+                        put((unsigned long)p, co, epilogue_f32(acc[j][r], true, mean[j], rinv[j], scale[j], bias[j], Y2H_ACT_LEAKY),
+                            co < a.Cout && p < a.npix);
+                    }
+                }
+            }
+        };
+        auto overlap = [&](const float (&av)[14], f32x16 (&acc_next)[NT], long tile_prev, const f32x16 (&acc_prev)[NT]) {
+            mfma_tile(av, acc_next);
+            finish_tile(tile_prev, acc_prev);
+#pragma unroll
+            for (int t = 0; t < 14 * NT; ++t) {          // one MFMA, then a share of the epilogue's VALU work and a store
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, POOL ? 14 : 13, 0);
+                __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            }
+        };
+        float a0[14], a1[14];
+        f32x16 accA[NT], accB[NT];
+        long cur = t_begin;
+        load_tile(a0);
+        if (cur + 1 < t_end) load_tile(a1);
+        mfma_tile(a0, accA);
+        for (;;) {
+            // accA holds tile cur, a1 the inputs of cur + 1
+            if (cur + 1 >= t_end) { finish_tile(cur, accA); break; }
+            if (cur + 2 < t_end) load_tile(a0);
+            overlap(a1, accB, cur, accA);
+            ++cur;
+            // accB holds tile cur, a0 the inputs of cur + 1
+            if (cur + 1 >= t_end) { finish_tile(cur, accB); break; }
+            if (cur + 2 < t_end) load_tile(a1);
+            overlap(a0, accA, cur, accB);
+            ++cur;
+        }
+    };
+    if (a.pool) { if (a.y_f16) pipelined(std::true_type{}, std::true_type{}); else pipelined(std::true_type{}, std::false_type{}); }
+    else { if (a.y_f16) pipelined(std::false_type{}, std::true_type{}); else pipelined(std::false_type{}, std::false_type{}); }
 }
 
 // ---------------------------------------------------------------------------
