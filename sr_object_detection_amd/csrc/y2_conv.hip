@@ -303,51 +303,60 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     __builtin_amdgcn_s_setprio(0);
 
     // epilogue: lane holds column (cout) li of each 32x32 tile and 16 rows (pixels)
+    // (`bn` and `act` are uniform, but tested per output value they are real branches -- 1439 s_cbranch in the 192x256
+    // instantiation; the common batch-norm + leaky case is compiled with both as constants)
+    auto epilogue_pass = [&](auto FASTC) {
+        constexpr bool FAST = decltype(FASTC)::value;
+        const bool BN_ = FAST ? true : (bool)a.bn;
+        const int ACT_ = FAST ? (int)Y2H_ACT_LEAKY : a.act;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wn * (BN / WN) + j * 32 + li;
-        const bool cok = co < a.Cout;
-        float mean = 0.f, scale = 1.f, bias = 0.f;
-        double rinv = 1.0;
-        if (cok) {
-            bias = a.bias[co];
-            if (a.bn) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int prow = p0 + wm * (BM / WM) + i * 32 + 4 * lh;
-            if (a.ksplit > 1) {
-                // split-K: raw partial sums to the workspace [split][pixel][filter]; splitk_reduce_kernel
-                // adds the splits in a fixed order (reproducible) and applies the epilogue
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = prow + (r & 3) + 8 * (r >> 2);
-                    if (cok && p < a.npix) a.ws[((size_t)ks * a.npix + p) * a.Cout + co] = acc[i][j][r];
-                }
-                continue;
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn * (BN / WN) + j * 32 + li;
+            const bool cok = co < a.Cout;
+            float mean = 0.f, scale = 1.f, bias = 0.f;
+            double rinv = 1.0;
+            if (cok) {
+                bias = a.bias[co];
+                if (BN_) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
             }
-            if (a.pool) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int r0 = prow + 8 * g;              // first of the window's four rows
-                    float m = epilogue_f32(acc[i][j][4 * g], a.bn, mean, rinv, scale, bias, a.act);
+            for (int i = 0; i < TM; ++i) {
+                const int prow = p0 + wm * (BM / WM) + i * 32 + 4 * lh;
+                if (a.ksplit > 1) {
+                    // split-K: raw partial sums to the workspace [split][pixel][filter]; splitk_reduce_kernel
+                    // adds the splits in a fixed order (reproducible) and applies the epilogue
 #pragma unroll
-                    for (int t = 1; t < 4; ++t) {
-                        const float v = epilogue_f32(acc[i][j][4 * g + t], a.bn, mean, rinv, scale, bias, a.act);
-                        m = (v > m) ? v : m;
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = prow + (r & 3) + 8 * (r >> 2);
+                        if (cok && p < a.npix) a.ws[((size_t)ks * a.npix + p) * a.Cout + co] = acc[i][j][r];
                     }
-                    if (cok && r0 < a.npix) a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
+                    continue;
                 }
-            } else {
+                if (a.pool) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = prow + (r & 3) + 8 * (r >> 2);
-                    if (cok && p < a.npix)
-                        a.y[(size_t)p * a.ldy + co] = epilogue_f32(acc[i][j][r], a.bn, mean, rinv, scale, bias, a.act);
+                    for (int g = 0; g < 4; ++g) {
+                        const int r0 = prow + 8 * g;              // first of the window's four rows
+                        float m = epilogue_f32(acc[i][j][4 * g], BN_, mean, rinv, scale, bias, ACT_);
+#pragma unroll
+                        for (int t = 1; t < 4; ++t) {
+                            const float v = epilogue_f32(acc[i][j][4 * g + t], BN_, mean, rinv, scale, bias, ACT_);
+                            m = (v > m) ? v : m;
+                        }
+                        if (cok && r0 < a.npix) a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = prow + (r & 3) + 8 * (r >> 2);
+                        if (cok && p < a.npix)
+                            a.y[(size_t)p * a.ldy + co] = epilogue_f32(acc[i][j][r], BN_, mean, rinv, scale, bias, ACT_);
+                    }
                 }
             }
         }
-    }
+    };
+    if (a.bn && a.act == Y2H_ACT_LEAKY) epilogue_pass(std::true_type{});
+    else epilogue_pass(std::false_type{});
     }   // tile loop
 }
 

@@ -17,6 +17,7 @@
 // LDS rows padded by 16 bytes so the ds_read_b128 operand reads (8 halves = the k-fragment of one
 // lane of a 32x32x16 MFMA) are bank-conflict free.
 #include "y2_conv_shared.hpp"
+#include <type_traits>
 
 // Tuning ablations (profiles/r01_notes.md): build with -DY2_F16_ABLATE and set Y2_DBG to a mask of
 // 1 no LDS staging writes, 2 no global loads, 4 no output stores, 8 scalar output stores, 16 no barrier,
@@ -852,81 +853,90 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(ConvK a)
                 av[s][u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off, 0, 0));
             }
     };
-    auto compute_tile = [&](long tile, const u32x2 (&av)[3][2]) {
-        f32x16 acc[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            u32x4 q;
-            q[0] = av[s][0][0]; q[1] = av[s][0][1]; q[2] = av[s][1][0]; q[3] = av[s][1][1];
-            const f16x8 af = __builtin_bit_cast(f16x8, q);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bw[j][s], acc[j], 0, 0, 0);
-        }
-        const long prow = tile * 32 + 4 * lh;
-        _Float16 *yh = (_Float16 *)a.y;
-        if (a.pool && a.vec_store) {
-            // half outputs as 16-byte stores: the tile's 8 pooled pixels x 32*NT filters go through a wave-private LDS
-            // scratch (2-byte stores cost several MFMA times each; LDS operations of one wave execute in order)
-            unsigned char *es = first_es + (threadIdx.x >> 6) * 8 * 144;
+    // The per-output tests of `act` (and of pool / store form) are uniform but real branches; left at run time they cut the
+    // epilogue into hundreds of basic blocks (856 s_cbranch in this kernel).  The loop is therefore compiled twice: once
+    // with the case that matters -- leaky, fused pool, 16-byte half stores -- as constants, once generic.
+    auto run = [&](auto FASTC) {
+        constexpr bool FAST = decltype(FASTC)::value;
+        const int ACT_ = FAST ? (int)Y2H_ACT_LEAKY : a.act;
+        auto compute_tile = [&](long tile, const u32x2 (&av)[3][2]) {
+            f32x16 acc[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], a.act);
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
-                    for (int t = 1; t < 4; ++t) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + t], alpha[j], beta[j], a.act));
-                    *(_Float16 *)(es + (2 * g + lh) * 144 + (32 * j + li) * 2) = (_Float16)m;
-                }
-            const u32x4 v = *(const u32x4 *)(es + (lane >> 3) * 144 + (lane & 7) * 16);
-            const long pr = tile * 8 + (lane >> 3);
-            if ((lane & 7) * 8 < a.Cout && pr * 4 < a.npix) *(u32x4 *)&yh[(size_t)pr * a.ldy + (lane & 7) * 8] = v;
-            return;
-        }
+            for (int s = 0; s < 3; ++s) {
+                u32x4 q;
+                q[0] = av[s][0][0]; q[1] = av[s][0][1]; q[2] = av[s][1][0]; q[3] = av[s][1][1];
+                const f16x8 af = __builtin_bit_cast(f16x8, q);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int co = j * 32 + li;
-            if (a.pool) {
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bw[j][s], acc[j], 0, 0, 0);
+            }
+            const long prow = tile * 32 + 4 * lh;
+            _Float16 *yh = (_Float16 *)a.y;
+            if (FAST || (a.pool && a.vec_store)) {
+                // half outputs as 16-byte stores: the tile's 8 pooled pixels x 32*NT filters go through a wave-private LDS
+                // scratch (2-byte stores cost several MFMA times each; LDS operations of one wave execute in order)
+                unsigned char *es = first_es + (threadIdx.x >> 6) * 8 * 144;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const long r0 = prow + 8 * g;
-                    float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], a.act);
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-                    for (int t = 1; t < 4; ++t) {
-                        const float v = epilogue_fast(acc[j][4 * g + t], alpha[j], beta[j], a.act);
-                        m = (v > m) ? v : m;
+                    for (int g = 0; g < 4; ++g) {
+                        float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], ACT_);
+#pragma unroll
+                        for (int t = 1; t < 4; ++t) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + t], alpha[j], beta[j], ACT_));
+                        *(_Float16 *)(es + (2 * g + lh) * 144 + (32 * j + li) * 2) = (_Float16)m;
                     }
-                    if (co < a.Cout && r0 < a.npix) {
-                        const size_t o = (size_t)(r0 >> 2) * a.ldy + co;
-                        if (a.y_f16) yh[o] = (_Float16)m; else a.y[o] = m;
-                    }
-                }
-                continue;
+                const u32x4 v = *(const u32x4 *)(es + (lane >> 3) * 144 + (lane & 7) * 16);
+                const long pr = tile * 8 + (lane >> 3);
+                if ((lane & 7) * 8 < a.Cout && pr * 4 < a.npix) *(u32x4 *)&yh[(size_t)pr * a.ldy + (lane & 7) * 8] = v;
+                return;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long p = prow + (r & 3) + 8 * (r >> 2);
-                if (co < a.Cout && p < a.npix) {
-                    const float v = epilogue_fast(acc[j][r], alpha[j], beta[j], a.act);
-                    const size_t o = (size_t)p * a.ldy + co;
-                    if (a.y_f16) yh[o] = (_Float16)v; else a.y[o] = v;
+            for (int j = 0; j < NT; ++j) {
+                const int co = j * 32 + li;
+                if (a.pool) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const long r0 = prow + 8 * g;
+                        float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], ACT_);
+#pragma unroll
+                        for (int t = 1; t < 4; ++t) {
+                            const float v = epilogue_fast(acc[j][4 * g + t], alpha[j], beta[j], ACT_);
+                            m = (v > m) ? v : m;
+                        }
+                        if (co < a.Cout && r0 < a.npix) {
+                            const size_t o = (size_t)(r0 >> 2) * a.ldy + co;
+                            if (a.y_f16) yh[o] = (_Float16)m; else a.y[o] = m;
+                        }
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long p = prow + (r & 3) + 8 * (r >> 2);
+                    if (co < a.Cout && p < a.npix) {
+                        const float v = epilogue_fast(acc[j][r], alpha[j], beta[j], ACT_);
+                        const size_t o = (size_t)p * a.ldy + co;
+                        if (a.y_f16) yh[o] = (_Float16)v; else a.y[o] = v;
+                    }
                 }
             }
+        };
+
+        u32x2 a0[3][2], a1[3][2];
+        long tile = t_begin;
+        if (tile < t_end) load_tile(a0);
+        for (; tile < t_end; tile += 2) {
+            if (tile + 1 < t_end) load_tile(a1);
+            compute_tile(tile, a0);
+            if (tile + 2 < t_end) load_tile(a0);
+            if (tile + 1 < t_end) compute_tile(tile + 1, a1);
         }
     };
-
-    u32x2 a0[3][2], a1[3][2];
-    long tile = t_begin;
-    if (tile < t_end) load_tile(a0);
-    for (; tile < t_end; tile += 2) {
-        if (tile + 1 < t_end) load_tile(a1);
-        compute_tile(tile, a0);
-        if (tile + 2 < t_end) load_tile(a0);
-        if (tile + 1 < t_end) compute_tile(tile + 1, a1);
-    }
+    if (a.act == Y2H_ACT_LEAKY && a.pool && a.vec_store) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 // x is the half NHWC4 haloed input (x_f16 = 1, x_halo = 1, ldx = 4), weights are the fp32 packed [n][27]
