@@ -285,156 +285,163 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
             cur ^= 1;
         }
 
-        _Float16 *yh = (_Float16 *)a.y;
-        if constexpr (M16) {
-            // 16x16 tiles: lane (l16, lq) holds filter l16 and GEMM rows 4*lq .. 4*lq+3 -- with the fused pool exactly
-            // one pooling window.  Two filter tiles (32 filters = 64 bytes per pixel) go through the LDS scratch
-            // together and leave as 16-byte stores (the host selects this variant only when that is possible).
-            constexpr int ES = 40;
-            static_assert(BUF >= WM * WN * 32 * ES, "epilogue scratch must fit in one staging buffer");
-            _Float16 *es = smem_h + (cur ^ 1) * BUF + wv * 32 * ES;
-            const int l16 = lane & 15, lq = lane >> 4;
-            const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
-            if (a.pool) {
-#pragma unroll
-                for (int jp = 0; jp < TN; ++jp) {
-                    const int cb = n0 + wn * (BN / WN) + jp * 32;
-                    const int c0f = cb + l16, c1f = cb + 16 + l16;
-                    const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
-                    const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
-#pragma unroll
-                    for (int ip = 0; ip < TM; ++ip) {                 // two 16-row tiles = 8 pooled rows
-                        const int pb = p0 + wm * (BM / WM) + ip * 32;
-#pragma unroll
-                        for (int ti = 0; ti < 2; ++ti) {
-                            const f32x4 q0 = acc6[2 * ip + ti][2 * jp], q1 = acc6[2 * ip + ti][2 * jp + 1];
-                            float m0 = epilogue_fast(q0[0], al0, be0, a.act), m1 = epilogue_fast(q1[0], al1, be1, a.act);
-#pragma unroll
-                            for (int u = 1; u < 4; ++u) {
-                                m0 = __builtin_fmaxf(m0, epilogue_fast(q0[u], al0, be0, a.act));
-                                m1 = __builtin_fmaxf(m1, epilogue_fast(q1[u], al1, be1, a.act));
-                            }
-                            es[(ti * 4 + lq) * ES + l16] = (_Float16)m0;
-                            es[(ti * 4 + lq) * ES + 16 + l16] = (_Float16)m1;
-                        }
-                        const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
-                        const int prow = (pb >> 2) + rrow;
-                        if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int jp = 0; jp < TN; ++jp) {
-                    const int cb = n0 + wn * (BN / WN) + jp * 32;
-                    const int c0f = cb + l16, c1f = cb + 16 + l16;
-                    const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
-                    const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
-#pragma unroll
-                    for (int i6 = 0; i6 < TM6; ++i6) {
-                        const int pb = p0 + wm * (BM / WM) + i6 * 16;
-                        const f32x4 q0 = acc6[i6][2 * jp], q1 = acc6[i6][2 * jp + 1];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            es[(lq * 4 + r) * ES + l16] = (_Float16)epilogue_fast(q0[r], al0, be0, a.act);
-                            es[(lq * 4 + r) * ES + 16 + l16] = (_Float16)epilogue_fast(q1[r], al1, be1, a.act);
-                        }
-                        const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
-                        const int p = pb + rrow;
-                        if (p < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
-                    }
-                }
-            }
-            __syncthreads();
-            continue;
-        }
-        // epilogue: lane holds filter li of each 32x32 tile and 16 pixels
-        if (a.vec_store) {
-            // Half outputs go out as 16-byte stores: a lane of the accumulator layout owns ONE filter of 16
-            // pixels, which would be sixteen 2-byte stores per 32x32 tile (measured: 38 % of the kernel).  Each
-            // wave transposes its tiles through 2.5 KB of the LDS buffer the K loop has just released (the other
-            // buffer already holds the next tile's first slice): 16 ds_write_b16, 2 ds_read_b128, 2 stores of
-            // 8 consecutive filters per lane.  LDS operations of one wave execute in order, so the wave-private
-            // scratch needs no barrier; the workgroup barrier below keeps the next K-step's staging writes out.
-            constexpr int ES = 40;                 // scratch row stride in halves (32 filters + 16 bytes)
-            static_assert(BUF >= WM * WN * 32 * ES, "epilogue scratch must fit in one staging buffer");
-            _Float16 *es = smem_h + (cur ^ 1) * BUF + wv * 32 * ES;
-            const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int cb = n0 + wn * (BN / WN) + j * 32;       // first filter of this 32-wide tile
-                const int co = cb + li;
-                const bool cok = co < a.Cout;
-                const float alpha = cok ? a.alpha[co] : 0.f, beta = cok ? a.beta[co] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int pb = p0 + wm * (BM / WM) + i * 32;   // first GEMM row of this tile
-                    if (a.pool) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            float m = epilogue_fast(acc[i][j][4 * g], alpha, beta, a.act);
-#pragma unroll
-                            for (int u = 1; u < 4; ++u) {
-                                const float v = epilogue_fast(acc[i][j][4 * g + u], alpha, beta, a.act);
-                                m = (v > m) ? v : m;
-                            }
-                            es[(2 * g + lh) * ES + li] = (_Float16)m;       // pooled row (pb + 8g + 4lh) / 4 - pb / 4
-                        }
-                        const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
-                        const int prow = (pb >> 2) + rrow;
-                        if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout && !ABL(4))
-                            *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + li] = (_Float16)epilogue_fast(acc[i][j][r], alpha, beta, a.act);
-#pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2) {
-                            const f32x4 v = *(const f32x4 *)&es[(rrow + 16 * h2) * ES + rchunk];
-                            const int p = pb + rrow + 16 * h2;
-                            if (p < a.npix && cb + rchunk < a.Cout && !ABL(4)) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn * (BN / WN) + j * 32 + li;
-            const bool cok = co < a.Cout && !ABL(4);
-            const float alpha = cok ? a.alpha[co] : 0.f, beta = cok ? a.beta[co] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int prow = p0 + wm * (BM / WM) + i * 32 + 4 * lh;
+        // (the activation is uniform, but tested per output value it is a real branch -- 1844 s_cbranch in the 256x256
+        // instantiation; the leaky case is compiled with it as a constant)
+        auto epilogue_pass = [&](auto LEAKYC) {
+            const int ACT_ = decltype(LEAKYC)::value ? (int)Y2H_ACT_LEAKY : a.act;
+            _Float16 *yh = (_Float16 *)a.y;
+            if constexpr (M16) {
+                // 16x16 tiles: lane (l16, lq) holds filter l16 and GEMM rows 4*lq .. 4*lq+3 -- with the fused pool exactly
+                // one pooling window.  Two filter tiles (32 filters = 64 bytes per pixel) go through the LDS scratch
+                // together and leave as 16-byte stores (the host selects this variant only when that is possible).
+                constexpr int ES = 40;
+                static_assert(BUF >= WM * WN * 32 * ES, "epilogue scratch must fit in one staging buffer");
+                _Float16 *es = smem_h + (cur ^ 1) * BUF + wv * 32 * ES;
+                const int l16 = lane & 15, lq = lane >> 4;
+                const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
                 if (a.pool) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int r0 = prow + 8 * g;
-                        float m = epilogue_fast(acc[i][j][4 * g], alpha, beta, a.act);
+                    for (int jp = 0; jp < TN; ++jp) {
+                        const int cb = n0 + wn * (BN / WN) + jp * 32;
+                        const int c0f = cb + l16, c1f = cb + 16 + l16;
+                        const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
+                        const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
 #pragma unroll
-                        for (int u = 1; u < 4; ++u) {
-                            const float v = epilogue_fast(acc[i][j][4 * g + u], alpha, beta, a.act);
-                            m = (v > m) ? v : m;
-                        }
-                        if (cok && r0 < a.npix) {
-                            const size_t o = (size_t)(r0 >> 2) * a.ldy + co;
-                            if (a.y_f16) yh[o] = (_Float16)m; else a.y[o] = m;
+                        for (int ip = 0; ip < TM; ++ip) {                 // two 16-row tiles = 8 pooled rows
+                            const int pb = p0 + wm * (BM / WM) + ip * 32;
+#pragma unroll
+                            for (int ti = 0; ti < 2; ++ti) {
+                                const f32x4 q0 = acc6[2 * ip + ti][2 * jp], q1 = acc6[2 * ip + ti][2 * jp + 1];
+                                float m0 = epilogue_fast(q0[0], al0, be0, ACT_), m1 = epilogue_fast(q1[0], al1, be1, ACT_);
+#pragma unroll
+                                for (int u = 1; u < 4; ++u) {
+                                    m0 = __builtin_fmaxf(m0, epilogue_fast(q0[u], al0, be0, ACT_));
+                                    m1 = __builtin_fmaxf(m1, epilogue_fast(q1[u], al1, be1, ACT_));
+                                }
+                                es[(ti * 4 + lq) * ES + l16] = (_Float16)m0;
+                                es[(ti * 4 + lq) * ES + 16 + l16] = (_Float16)m1;
+                            }
+                            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+                            const int prow = (pb >> 2) + rrow;
+                            if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int p = prow + (r & 3) + 8 * (r >> 2);
-                        if (cok && p < a.npix) {
-                            const float v = epilogue_fast(acc[i][j][r], alpha, beta, a.act);
-                            const size_t o = (size_t)p * a.ldy + co;
-                            if (a.y_f16) yh[o] = (_Float16)v; else a.y[o] = v;
+                    for (int jp = 0; jp < TN; ++jp) {
+                        const int cb = n0 + wn * (BN / WN) + jp * 32;
+                        const int c0f = cb + l16, c1f = cb + 16 + l16;
+                        const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
+                        const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
+#pragma unroll
+                        for (int i6 = 0; i6 < TM6; ++i6) {
+                            const int pb = p0 + wm * (BM / WM) + i6 * 16;
+                            const f32x4 q0 = acc6[i6][2 * jp], q1 = acc6[i6][2 * jp + 1];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                es[(lq * 4 + r) * ES + l16] = (_Float16)epilogue_fast(q0[r], al0, be0, ACT_);
+                                es[(lq * 4 + r) * ES + 16 + l16] = (_Float16)epilogue_fast(q1[r], al1, be1, ACT_);
+                            }
+                            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+                            const int p = pb + rrow;
+                            if (p < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+                return;
+            }
+            // epilogue: lane holds filter li of each 32x32 tile and 16 pixels
+            if (a.vec_store) {
+                // Half outputs go out as 16-byte stores: a lane of the accumulator layout owns ONE filter of 16
+                // pixels, which would be sixteen 2-byte stores per 32x32 tile (measured: 38 % of the kernel).  Each
+                // wave transposes its tiles through 2.5 KB of the LDS buffer the K loop has just released (the other
+                // buffer already holds the next tile's first slice): 16 ds_write_b16, 2 ds_read_b128, 2 stores of
+                // 8 consecutive filters per lane.  LDS operations of one wave execute in order, so the wave-private
+                // scratch needs no barrier; the workgroup barrier below keeps the next K-step's staging writes out.
+                constexpr int ES = 40;                 // scratch row stride in halves (32 filters + 16 bytes)
+                static_assert(BUF >= WM * WN * 32 * ES, "epilogue scratch must fit in one staging buffer");
+                _Float16 *es = smem_h + (cur ^ 1) * BUF + wv * 32 * ES;
+                const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int cb = n0 + wn * (BN / WN) + j * 32;       // first filter of this 32-wide tile
+                    const int co = cb + li;
+                    const bool cok = co < a.Cout;
+                    const float alpha = cok ? a.alpha[co] : 0.f, beta = cok ? a.beta[co] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int pb = p0 + wm * (BM / WM) + i * 32;   // first GEMM row of this tile
+                        if (a.pool) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                float m = epilogue_fast(acc[i][j][4 * g], alpha, beta, ACT_);
+#pragma unroll
+                                for (int u = 1; u < 4; ++u) {
+                                    const float v = epilogue_fast(acc[i][j][4 * g + u], alpha, beta, ACT_);
+                                    m = (v > m) ? v : m;
+                                }
+                                es[(2 * g + lh) * ES + li] = (_Float16)m;       // pooled row (pb + 8g + 4lh) / 4 - pb / 4
+                            }
+                            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+                            const int prow = (pb >> 2) + rrow;
+                            if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout && !ABL(4))
+                                *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + li] = (_Float16)epilogue_fast(acc[i][j][r], alpha, beta, ACT_);
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const f32x4 v = *(const f32x4 *)&es[(rrow + 16 * h2) * ES + rchunk];
+                                const int p = pb + rrow + 16 * h2;
+                                if (p < a.npix && cb + rchunk < a.Cout && !ABL(4)) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int co = n0 + wn * (BN / WN) + j * 32 + li;
+                const bool cok = co < a.Cout && !ABL(4);
+                const float alpha = cok ? a.alpha[co] : 0.f, beta = cok ? a.beta[co] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int prow = p0 + wm * (BM / WM) + i * 32 + 4 * lh;
+                    if (a.pool) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int r0 = prow + 8 * g;
+                            float m = epilogue_fast(acc[i][j][4 * g], alpha, beta, ACT_);
+#pragma unroll
+                            for (int u = 1; u < 4; ++u) {
+                                const float v = epilogue_fast(acc[i][j][4 * g + u], alpha, beta, ACT_);
+                                m = (v > m) ? v : m;
+                            }
+                            if (cok && r0 < a.npix) {
+                                const size_t o = (size_t)(r0 >> 2) * a.ldy + co;
+                                if (a.y_f16) yh[o] = (_Float16)m; else a.y[o] = m;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int p = prow + (r & 3) + 8 * (r >> 2);
+                            if (cok && p < a.npix) {
+                                const float v = epilogue_fast(acc[i][j][r], alpha, beta, ACT_);
+                                const size_t o = (size_t)p * a.ldy + co;
+                                if (a.y_f16) yh[o] = (_Float16)v; else a.y[o] = v;
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if (a.act == Y2H_ACT_LEAKY) epilogue_pass(std::true_type{});
+        else epilogue_pass(std::false_type{});
     }
 }
 
@@ -490,9 +497,10 @@ static VariantH g_variants_h[] = {
 //     patch with one ds_read_b128 per tap and k-step, shared by both filter tiles: 0.5 LDS reads per MFMA (the generic
 //     kernel needs 0.75).  Pixel pitch 80 B and row pitch 1664 B make those reads bank-conflict free.
 // ---------------------------------------------------------------------------
-template <int NF, bool POOL>
+template <int NF, bool POOL, bool LEAKY>
 __global__ __launch_bounds__(256, 2) void conv_c32_f16_kernel(ConvK a)
 {
+    const int ACT_ = LEAKY ? (int)Y2H_ACT_LEAKY : a.act;     // a constant in the common case: no per-value branches
     constexpr int PW = 18, PIX_B = 80, ROW_B = 1664, BUF_B = PW * ROW_B;
     constexpr int NCH = PW * PW * 4;                 // 16-byte chunks of one patch
     constexpr int NP = (NCH + 255) / 256;            // staging passes
@@ -590,9 +598,9 @@ __global__ __launch_bounds__(256, 2) void conv_c32_f16_kernel(ConvK a)
                 for (int j = 0; j < NF; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], a.act);
+                        float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], ACT_);
 #pragma unroll
-                        for (int u = 1; u < 4; ++u) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + u], alpha[j], beta[j], a.act));
+                        for (int u = 1; u < 4; ++u) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + u], alpha[j], beta[j], ACT_));
                         *(_Float16 *)(es + (2 * g + lh) * ES_B + (32 * j + li) * 2) = (_Float16)m;
                     }
                 const u32x4 v = *(const u32x4 *)(es + (lane >> 3) * ES_B + (lane & 7) * 16);
@@ -607,9 +615,9 @@ __global__ __launch_bounds__(256, 2) void conv_c32_f16_kernel(ConvK a)
                     const size_t prow = ((size_t)n * Hp + (oy0 >> 1) + rp) * Wp + (ox0 >> 1);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], a.act);
+                        float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], ACT_);
 #pragma unroll
-                        for (int u = 1; u < 4; ++u) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + u], alpha[j], beta[j], a.act));
+                        for (int u = 1; u < 4; ++u) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + u], alpha[j], beta[j], ACT_));
                         if (co < a.Cout) yh[(prow + 2 * g + lh) * a.ldy + co] = (_Float16)m;
                     }
                 } else {
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void conv_c32_f16_kernel(ConvK a)
                         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;            // GEMM row = 4*window + corner
                         const int oy = oy0 + 2 * rp + ((rr >> 1) & 1), ox = ox0 + 2 * (rr >> 2) + (rr & 1);
                         if (co < a.Cout)
-                            yh[(((size_t)n * a.H + oy) * a.W + ox) * a.ldy + co] = (_Float16)epilogue_fast(acc[j][r], alpha[j], beta[j], a.act);
+                            yh[(((size_t)n * a.H + oy) * a.W + ox) * a.ldy + co] = (_Float16)epilogue_fast(acc[j][r], alpha[j], beta[j], ACT_);
                     }
                 }
             }
@@ -647,13 +655,16 @@ static int c32_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     a.xbytes = (unsigned)((size_t)d->batch * d->h * d->w * d->ldx * 2);
     a.wbytes = (unsigned)((size_t)d->n * 288 * 2);
     const int nf = d->n <= 32 ? 1 : 2;
-    void (*fn)(ConvK) = nf == 1 ? (a.pool ? conv_c32_f16_kernel<1, true> : conv_c32_f16_kernel<1, false>)
-                                : (a.pool ? conv_c32_f16_kernel<2, true> : conv_c32_f16_kernel<2, false>);
+    const bool lk = d->activation == Y2H_ACT_LEAKY;
+    void (*fn)(ConvK) = nf == 1 ? (a.pool ? (lk ? conv_c32_f16_kernel<1, true, true> : conv_c32_f16_kernel<1, true, false>)
+                                          : (lk ? conv_c32_f16_kernel<1, false, true> : conv_c32_f16_kernel<1, false, false>))
+                                : (a.pool ? (lk ? conv_c32_f16_kernel<2, true, true> : conv_c32_f16_kernel<2, true, false>)
+                                          : (lk ? conv_c32_f16_kernel<2, false, true> : conv_c32_f16_kernel<2, false, false>));
     const size_t lds = (size_t)2 * 18 * 1664 + 4 * 8 * 144;
     a.vec_store = d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !getenv("Y2_C32_SCALAR");
     {
-        static bool attr_set[16][4] = {{false}};         // per device and instantiation: the attribute call is not free
-        const int which = (nf - 1) * 2 + (a.pool ? 1 : 0);
+        static bool attr_set[16][8] = {{false}};         // per device and instantiation: the attribute call is not free
+        const int which = ((nf - 1) * 2 + (a.pool ? 1 : 0)) * 2 + (lk ? 1 : 0);
         int dev = 0;
         Y2H_CHECK(hipGetDevice(&dev));
         if (dev < 0 || dev >= 16 || !attr_set[dev][which]) {
