@@ -305,10 +305,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // epilogue: lane holds column (cout) li of each 32x32 tile and 16 rows (pixels)
     // (`bn` and `act` are uniform, but tested per output value they are real branches -- 1439 s_cbranch in the 192x256
     // instantiation; the common batch-norm + leaky case is compiled with both as constants)
-    auto epilogue_pass = [&](auto FASTC) {
-        constexpr bool FAST = decltype(FASTC)::value;
-        const bool BN_ = FAST ? true : (bool)a.bn;
-        const int ACT_ = FAST ? (int)Y2H_ACT_LEAKY : a.act;
+    auto epilogue_pass = [&](auto MODEC) {
+        constexpr int MODE = decltype(MODEC)::value;        // 0 run-time bn / act, 1 batch-norm + leaky, 2 batch-norm + linear
+        const bool BN_ = MODE ? true : (bool)a.bn;
+        const int ACT_ = MODE == 1 ? (int)Y2H_ACT_LEAKY : MODE == 2 ? (int)Y2H_ACT_LINEAR : a.act;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int co = n0 + wn * (BN / WN) + j * 32 + li;
@@ -355,8 +355,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             }
         }
     };
-    if (a.bn && a.act == Y2H_ACT_LEAKY) epilogue_pass(std::true_type{});
-    else epilogue_pass(std::false_type{});
+    if (a.bn && a.act == Y2H_ACT_LEAKY) epilogue_pass(std::integral_constant<int, 1>{});
+    else if (a.bn && a.act == Y2H_ACT_LINEAR) epilogue_pass(std::integral_constant<int, 2>{});     // resnet's 1x1 expansions
+    else epilogue_pass(std::integral_constant<int, 0>{});
     }   // tile loop
 }
 

@@ -391,9 +391,11 @@ __global__ __launch_bounds__(256) void shortcut_kernel(const float *__restrict__
 
 // the common case -- both operands of the same shape (every [shortcut] of resnet50.cfg but the three that change width),
 // channels a multiple of 4: 16-byte loads and stores, no coordinate decode
+template <int ACT>        // a Y2H_ACT_* code compiled in, or -1: taken from `act_rt` (a per-value branch)
 __global__ __launch_bounds__(256) void shortcut_same_kernel(const float *__restrict__ in, int ld_in, const float *__restrict__ add,
-                                                            int ld_add, float *__restrict__ out, int ld_out, int c4, int act, long total)
+                                                            int ld_add, float *__restrict__ out, int ld_out, int c4, int act_rt, long total)
 {
+    const int act = ACT >= 0 ? ACT : act_rt;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long pix = idx / c4;
         const int k = (int)(idx - pix * c4) * 4;
@@ -413,7 +415,10 @@ extern "C" int y2h_shortcut(const float *in, int ld_in, const float *add, int ld
     if (w1 == w2 && h1 == h2 && c1 == c2 && c2 % 4 == 0 && ld_in % 4 == 0 && ld_add % 4 == 0 && ld_out % 4 == 0 &&
         (((uintptr_t)in | (uintptr_t)add | (uintptr_t)out) & 15) == 0) {
         const long total4 = (long)batch * h2 * w2 * (c2 / 4);
-        hipLaunchKernelGGL(shortcut_same_kernel, dim3(y2h_grid(total4, 256)), dim3(256), 0, S(s), in, ld_in, add, ld_add, out, ld_out,
+        void (*fn)(const float *, int, const float *, int, float *, int, int, int, long) =
+            activation == Y2H_ACT_LEAKY ? shortcut_same_kernel<Y2H_ACT_LEAKY> :
+            activation == Y2H_ACT_LINEAR ? shortcut_same_kernel<Y2H_ACT_LINEAR> : shortcut_same_kernel<-1>;
+        hipLaunchKernelGGL(fn, dim3(y2h_grid(total4, 256)), dim3(256), 0, S(s), in, ld_in, add, ld_add, out, ld_out,
                            c2 / 4, activation, total4);
         Y2H_LAUNCH_CHECK();
         return Y2H_OK;
