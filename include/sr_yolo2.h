@@ -293,6 +293,11 @@ int y2_forward_device(network net, const float *d_input);
  * detections per image are written to dets[b*max_per_image ...], counts[b] = number found. */
 int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_h,
                        y2_det *dets, int *counts, int max_per_image);
+/* Its two halves, for callers that keep the device busy across batches: y2_detect_enqueue(i); y2_forward_device(i+1);
+ * y2_detect_fetch(i) -- the fetch waits for batch i's results only (an event behind their D2H copies), so the host-side
+ * wait and unpacking overlap the next forward pass.  One enqueue may be outstanding per network. */
+int y2_detect_enqueue(network net, float thresh, float nms, int img_w, int img_h);
+int y2_detect_fetch(network net, y2_det *dets, int *counts, int max_per_image);
 /* Same on the average of the last three forwards' region outputs (Detector::detect use_mean, yolo_v2_class.cpp:
  * 208-213): the three-slot ring and the average live in HBM; slots start zeroed like the reference's calloc. */
 int y2_detect_mean(network net, float thresh, float nms, int img_w, int img_h,

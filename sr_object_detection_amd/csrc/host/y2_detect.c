@@ -267,20 +267,24 @@ image resize_image(image im, int w, int h)   /* image.c:1950-1992, on the device
 /* ------------------------------------------------------------------ */
 /* fused, HBM-resident detection                                       */
 /* ------------------------------------------------------------------ */
-static int detect_from(network net, float *d_pred, float thresh, float nms, int img_w, int img_h,
-                       y2_det *dets, int *counts, int max_per_image)
+/* Decode + NMS + compaction are enqueued by detect_enqueue (with the D2H copies of the counts and, when they are
+ * small, of the record blocks, followed by an event); detect_fetch waits for that event only -- not for whatever the
+ * caller has enqueued behind it, e.g. the next batch's forward pass -- and unpacks.  y2_detect_resident = both. */
+static int detect_enqueue(network net, float *d_pred, float thresh, float nms, int img_w, int img_h)
 {
     y2_engine *e = y2_engine_of(&net);
     layer *l;
     y2_ldev *d;
     y2h_decode q;
     const float *final_probs;
-    int b, i, keep;
+    int b, keep;
     if (!e || !e->built) { y2_fail("y2_detect_resident: run a forward first"); return -1; }
     l = &net.layers[e->out_layer];
     d = ld_of(l);
     if (l->type != REGION && l->type != DETECTION) { y2_fail("y2_detect_resident: the network does not end in a region or detection layer"); return -1; }
     HIPCALL_I(y2h_set_device(e->device));
+    e->det_pending = 0;
+    if (!e->ev_det) HIPCALL_I(y2h_event_create(&e->ev_det));
     if (!d_pred) d_pred = l->type == REGION ? d->d_region : d->d_flat;
     memset(&q, 0, sizeof q);
     if (l->type == DETECTION) {           /* YOLOv1 head: detection_layer.c:222 decode, then the same NMS / compaction */
@@ -308,7 +312,9 @@ static int detect_from(network net, float *d_pred, float thresh, float nms, int 
     if ((size_t)net.batch * e->det_cap * 6 * sizeof(float) <= ((size_t)8 << 20)) {
         /* small enough: fetch every record block with the counts, one copy and one sync per batch */
         HIPCALL_I(y2h_memcpy_d2h(e->h_records, e->d_records, (size_t)net.batch * e->det_cap * 6 * sizeof(float), e->stream));
-        HIPCALL_I(y2h_stream_sync(e->stream));
+        HIPCALL_I(y2h_event_record(e->ev_det, e->stream));
+        e->det_pending = 1;                   /* detect_fetch waits for the event */
+        return 0;
     } else {
         HIPCALL_I(y2h_stream_sync(e->stream));
         for (b = 0; b < net.batch; ++b) if (e->h_counts[b] > keep) keep = e->h_counts[b];
@@ -324,6 +330,17 @@ static int detect_from(network net, float *d_pred, float thresh, float nms, int 
         }
         HIPCALL_I(y2h_stream_sync(e->stream));
     }
+    e->det_pending = 2;                       /* wide heads (yolo9000): fetched synchronously above */
+    return 0;
+}
+
+static int detect_fetch(network net, y2_det *dets, int *counts, int max_per_image)
+{
+    y2_engine *e = y2_engine_of(&net);
+    int b, i;
+    if (!e || !e->det_pending) { y2_fail("y2_detect_fetch: nothing was enqueued (call y2_detect_enqueue after a forward)"); return -1; }
+    if (e->det_pending == 1) HIPCALL_I(y2h_event_sync(e->ev_det));
+    e->det_pending = 0;
     for (b = 0; b < net.batch; ++b) {
         int nb = e->h_counts[b];
         counts[b] = nb;
@@ -338,10 +355,30 @@ static int detect_from(network net, float *d_pred, float thresh, float nms, int 
     return 0;
 }
 
+static int detect_from(network net, float *d_pred, float thresh, float nms, int img_w, int img_h,
+                       y2_det *dets, int *counts, int max_per_image)
+{
+    if (detect_enqueue(net, d_pred, thresh, nms, img_w, img_h) != 0) return -1;
+    return detect_fetch(net, dets, counts, max_per_image);
+}
+
 int y2_detect_resident(network net, float thresh, float nms, int img_w, int img_h,
                        y2_det *dets, int *counts, int max_per_image)
 {
     return detect_from(net, NULL, thresh, nms, img_w, img_h, dets, counts, max_per_image);
+}
+
+/* The two halves of y2_detect_resident for callers that keep the GPU busy across batches: enqueue batch i's decode /
+ * NMS / compaction, enqueue batch i+1's forward pass, then fetch batch i's detections -- the host-side wait and
+ * unpacking overlap the next forward instead of idling the device. */
+int y2_detect_enqueue(network net, float thresh, float nms, int img_w, int img_h)
+{
+    return detect_enqueue(net, NULL, thresh, nms, img_w, img_h);
+}
+
+int y2_detect_fetch(network net, y2_det *dets, int *counts, int max_per_image)
+{
+    return detect_fetch(net, dets, counts, max_per_image);
 }
 
 /* The 3-frame smoothing of Detector::detect(..., use_mean = true) (yolo_v2_class.cpp:208-213: memcpy into

@@ -146,6 +146,8 @@ void y2_engine_destroy(network *net)
     if (e->h_out_pinned) y2h_host_unregister(e->h_out);
     free(e->h_out);
     if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
+    if (e->ev_det) y2h_event_destroy(e->ev_det);
+    if (e->graph) y2h_graph_destroy(e->graph);
     y2h_stream_destroy(e->stream);
     free(e);
     net->engine = NULL;

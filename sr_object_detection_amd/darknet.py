@@ -423,6 +423,25 @@ class Network:
             raise Y2Error("y2_detect_resident: " + _check())
         return [dets[b, :min(int(counts[b]), cap)].copy() for b in range(self.net.batch)], counts
 
+    def detect_enqueue(self, thresh: float, nms: float, img_w: int = 1, img_h: int = 1) -> None:
+        """first half of detect_resident: decode + NMS + compaction + D2H enqueued, no wait (y2_detect_enqueue)"""
+        L = lib()
+        L.y2_detect_enqueue.argtypes = [CNetwork, C.c_float, C.c_float, C.c_int, C.c_int]
+        if L.y2_detect_enqueue(self.net, thresh, nms, img_w, img_h) != 0:
+            raise Y2Error("y2_detect_enqueue: " + _check())
+
+    def detect_fetch(self, max_per_image: int | None = None):
+        """second half: wait for the enqueued detections only and unpack them (y2_detect_fetch)"""
+        l = self.last
+        cap = max_per_image or (l.w * l.h * l.n)
+        dets = np.zeros((self.net.batch, cap), dtype=DET_DTYPE)
+        counts = np.zeros(self.net.batch, dtype=np.int32)
+        L = lib()
+        L.y2_detect_fetch.argtypes = [CNetwork, C.c_void_p, C.c_void_p, C.c_int]
+        if L.y2_detect_fetch(self.net, _ptr(dets), _ptr(counts), cap) != 0:
+            raise Y2Error("y2_detect_fetch: " + _check())
+        return [dets[b, :min(int(counts[b]), cap)].copy() for b in range(self.net.batch)], counts
+
     def detect_mean(self, thresh: float, nms: float, img_w: int = 1, img_h: int = 1):
         """decode + NMS of the average of the last three forwards (Detector use_mean, y2_detect_mean); batch 1"""
         l = self.last

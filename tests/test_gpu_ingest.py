@@ -135,3 +135,39 @@ def test_graph_replay_matches_direct_launches(workdir):
     net.set_graph(False)
     assert np.array_equal(net.network_predict(xa[:1]), one)
     net.free()
+
+
+def test_detect_enqueue_fetch_overlaps_the_next_forward(workdir):
+    """y2_detect_enqueue / y2_detect_fetch: the detections of batch i fetched after batch i+1's forward pass has been
+    enqueued are those of batch i (the fetch waits for its own event, the next forward does not disturb the record
+    buffers), identical to the synchronous y2_detect_resident"""
+    import os
+    import torch
+    from sr_object_detection_amd import synth, zoo
+    cfg = os.path.join(workdir, "pipe.cfg")
+    open(cfg, "w").write(zoo.cfg_text("mini-mfma", 64, 64, 3))
+    wts = os.path.join(workdir, "pipe.weights")
+    synth.write_weights(wts, zoo.resolve("mini-mfma", 64), 5)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    frames = [torch.from_numpy(synth.image_batch(3, 3, 64, 64, seed=10 + i)).cuda() for i in range(4)]
+    want = []
+    for f in frames:
+        net.forward_device(f.data_ptr())
+        want.append(net.detect_resident(0.3, 0.4))
+    assert sum(int(c.sum()) for _, c in want) > 10 and len({int(c.sum()) for _, c in want}) > 1
+    got = []
+    net.forward_device(frames[0].data_ptr())
+    net.detect_enqueue(0.3, 0.4)
+    for i in range(1, 4):
+        net.forward_device(frames[i].data_ptr())
+        got.append(net.detect_fetch())
+        net.detect_enqueue(0.3, 0.4)
+    got.append(net.detect_fetch())
+    for (gd, gc), (wd, wc) in zip(got, want):
+        assert np.array_equal(gc, wc)
+        for a, b in zip(gd, wd):
+            assert np.array_equal(a, b)
+    with pytest.raises(darknet.Y2Error):
+        net.detect_fetch()                      # nothing outstanding
+    net.free()
