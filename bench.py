@@ -286,22 +286,32 @@ def main():
                 per_kernel_flops[k] = per_kernel_flops.get(k, 0.0) + flops[i] * batch
                 per_kernel_launches[k] = per_kernel_launches.get(k, 0) + 1
 
-    pipelined = is_detector and not args.host_input and not os.environ.get("Y2_BENCH_NO_PIPELINE")
+    pipelined = not args.host_input and not os.environ.get("Y2_BENCH_NO_PIPELINE")
     barrier()
     t0 = time.perf_counter()
     if pipelined:
         # Every step is still one forward + one decode/NMS/collect + one fetch of the detections; the host side of step
         # i (waiting for its records, unpacking them) overlaps the device side of step i+1: y2_detect_fetch waits for an
         # event behind step i's D2H copies only, so the next forward is already queued when the host blocks.
+        # (a classifier's step is forward + host copy of the class scores: y2_output_enqueue / y2_output_fetch.)
+        def enqueue_results():
+            if is_detector:
+                net.detect_enqueue(THRESH, NMS)
+            else:
+                net.output_enqueue()
+
+        def fetch_results():
+            return net.detect_fetch() if is_detector else (net.output_fetch(), np.zeros(1))
+
         net.forward_device(d_x.data_ptr())
-        net.detect_enqueue(THRESH, NMS)
+        enqueue_results()
         for _ in range(args.steps - 1):
-            account_layer_times()                       # needs the previous forward's events, not its detections
+            account_layer_times()                       # needs the previous forward's events, not its results
             net.forward_device(d_x.data_ptr())
-            dets, counts = net.detect_fetch()
-            net.detect_enqueue(THRESH, NMS)
+            dets, counts = fetch_results()
+            enqueue_results()
         account_layer_times()
-        dets, counts = net.detect_fetch()
+        dets, counts = fetch_results()
     else:
         for _ in range(args.steps):
             dets, counts = step()

@@ -287,6 +287,11 @@ void y2_weights_resident(network *net);
 /* network_predict with the input already in HBM (NCHW, batch*inputs floats).  The returned
  * pointer is the same host buffer network_predict returns. */
 float *y2_network_predict_device(network net, const float *d_input);
+/* The host copy of the output as two halves, for callers that keep the device busy across batches (classifiers):
+ * y2_forward_device(i); y2_output_enqueue(); y2_forward_device(i+1); p = y2_output_fetch();  -- the fetch waits for
+ * batch i's copy only and returns the same host buffer network_predict returns (valid until the next enqueue). */
+int y2_output_enqueue(network net);
+float *y2_output_fetch(network net);
 /* Forward only (no host copy of the output); then decode+NMS+collect with y2_detect_resident. */
 int y2_forward_device(network net, const float *d_input);
 /* Decode + per-class NMS + compaction of the last forward, all on device; up to max_per_image

@@ -147,6 +147,7 @@ void y2_engine_destroy(network *net)
     free(e->h_out);
     if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
     if (e->ev_det) y2h_event_destroy(e->ev_det);
+    if (e->ev_out) y2h_event_destroy(e->ev_out);
     if (e->graph) y2h_graph_destroy(e->graph);
     y2h_stream_destroy(e->stream);
     free(e);
@@ -1023,6 +1024,41 @@ int y2_engine_fetch_output(network *net)
     HIPCALL(y2h_memcpy_d2h(e->h_out, src, e->out_floats * sizeof(float), e->stream));
     HIPCALL(y2h_stream_sync(e->stream));
     return 0;
+}
+
+/* the same copy without the wait: an event is recorded behind it for y2_output_fetch */
+int y2_output_enqueue(network net)
+{
+    y2_engine *e = y2_engine_of(&net);
+    layer *l;
+    y2_ldev *d;
+    const float *src;
+    if (!e || !e->built) { y2_fail("y2_output_enqueue: run a forward first"); return -1; }
+    l = &net.layers[e->out_layer];
+    d = ld_of(l);
+    HIPCALL(y2h_set_device(e->device));
+    if (!e->ev_out) HIPCALL(y2h_event_create(&e->ev_out));
+    if (is_flat(&net, e->out_layer)) src = d->out;
+    else {
+        if (d->out_half)
+            HIPCALL(y2h_nhwc_f16_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
+        else
+            HIPCALL(y2h_nhwc_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
+        src = e->d_out_nchw;
+    }
+    HIPCALL(y2h_memcpy_d2h(e->h_out, src, e->out_floats * sizeof(float), e->stream));
+    HIPCALL(y2h_event_record(e->ev_out, e->stream));
+    e->out_pending = 1;
+    return 0;
+}
+
+float *y2_output_fetch(network net)
+{
+    y2_engine *e = y2_engine_of(&net);
+    if (!e || !e->out_pending) { y2_fail("y2_output_fetch: nothing was enqueued (call y2_output_enqueue after a forward)"); return NULL; }
+    if (y2h_event_sync(e->ev_out) != 0) { y2_fail("y2_output_fetch: %s", y2h_last_error()); return NULL; }
+    e->out_pending = 0;
+    return e->h_out;
 }
 
 /* ------------------------------------------------------------------ */

@@ -54,6 +54,8 @@ typedef struct y2_engine {
     int in_halo;               /* the NHWC copy of the input carries a zero border (2: the half NHWC4 form) */
     int in_halo_px;            /* its width in pixels: 1 for the 3x3 first-layer kernels, the padding for the stem kernel */
     /* hipGraph replay of the forward launch sequence (y2_set_graph): recorded for one input pointer, dropped with the plan */
+    y2h_event ev_out;          /* recorded behind the output copy of y2_output_enqueue */
+    int out_pending;
     y2h_event ev_det;          /* recorded behind the D2H copies of y2_detect_enqueue */
     int det_pending;           /* 1: wait for ev_det in y2_detect_fetch, 2: already fetched synchronously */
     int graph_on;

@@ -423,6 +423,21 @@ class Network:
             raise Y2Error("y2_detect_resident: " + _check())
         return [dets[b, :min(int(counts[b]), cap)].copy() for b in range(self.net.batch)], counts
 
+    def output_enqueue(self) -> None:
+        L = lib()
+        L.y2_output_enqueue.argtypes = [CNetwork]
+        if L.y2_output_enqueue(self.net) != 0:
+            raise Y2Error("y2_output_enqueue: " + _check())
+
+    def output_fetch(self) -> np.ndarray:
+        L = lib()
+        L.y2_output_fetch.argtypes = [CNetwork]
+        L.y2_output_fetch.restype = C.POINTER(C.c_float)
+        p = L.y2_output_fetch(self.net)
+        if not p:
+            raise Y2Error("y2_output_fetch: " + _check())
+        return np.ctypeslib.as_array(p, shape=(self.net.batch * self.output_size,)).copy()
+
     def detect_enqueue(self, thresh: float, nms: float, img_w: int = 1, img_h: int = 1) -> None:
         """first half of detect_resident: decode + NMS + compaction + D2H enqueued, no wait (y2_detect_enqueue)"""
         L = lib()

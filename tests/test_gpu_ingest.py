@@ -171,3 +171,33 @@ def test_detect_enqueue_fetch_overlaps_the_next_forward(workdir):
     with pytest.raises(darknet.Y2Error):
         net.detect_fetch()                      # nothing outstanding
     net.free()
+
+
+def test_output_enqueue_fetch_matches_predict_device(workdir):
+    """y2_output_enqueue / y2_output_fetch (the classifier's overlapped host copy): batch i's scores fetched after batch
+    i+1's forward was enqueued equal y2_network_predict_device's"""
+    import os
+    import torch
+    from sr_object_detection_amd import synth, zoo
+    cfg = os.path.join(workdir, "pipe_cls.cfg")
+    open(cfg, "w").write(zoo.cfg_text("darknet-ref", 64, 64, 2))
+    wts = os.path.join(workdir, "pipe_cls.weights")
+    synth.write_weights(wts, zoo.resolve("darknet-ref", 64), 6, 1.0)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    frames = [torch.from_numpy(synth.image_batch(2, 3, 64, 64, seed=20 + i)).cuda() for i in range(3)]
+    want = [net.predict_device(f.data_ptr()) for f in frames]
+    assert not np.array_equal(want[0], want[1])
+    got = []
+    net.forward_device(frames[0].data_ptr())
+    net.output_enqueue()
+    for i in range(1, 3):
+        net.forward_device(frames[i].data_ptr())
+        got.append(net.output_fetch())
+        net.output_enqueue()
+    got.append(net.output_fetch())
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    with pytest.raises(darknet.Y2Error):
+        net.output_fetch()
+    net.free()
