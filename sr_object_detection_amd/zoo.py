@@ -188,6 +188,15 @@ SPECS["mini-xnor"] = [
     ("region", {"classes": 5, "num": 3, "anchors": [1.0, 1.2, 2.5, 2.0, 4.0, 3.5]}),
 ]
 
+# the shapes of the reference's classifier cfgs in one small net: 7x7/2 stem (resnet50 / extraction), 3x3/2 maxpool without
+# padding (alexnet), 5x5 convolution (alexnet), 2x2/2 maxpool with padding=1 (darknet.cfg), strided 3x3 and 1x1 convolutions
+# (resnet50 / strided.cfg), a residual shortcut across a stride, dense head with relu, softmax
+SPECS["mini-cls"] = [
+    ("conv", 16, 7, 1, "leaky", 2), ("max", 3, 2, 0), ("conv", 32, 5, 0, "relu"), ("max", 2, 2, 1),
+    ("conv", 32, 3, 1, "leaky", 2), ("conv", 64, 1, 1, "linear", 2), ("conv", 64, 3, 1, "leaky"), ("shortcut", -2, "leaky"),
+    ("connected", 48, 0, "relu"), ("dropout", 0.5), ("connected", 10, 0, "linear"), ("softmax",), ("cost",),
+]
+
 # every activation of activations.h:21-54 outside the four the target cfgs use (strided.cfg is all `ramp`): on
 # matrix-core convolutions, a strided one, a shortcut, and behind a placed (zero-copy) route source
 SPECS["mini-acts"] = [
@@ -211,7 +220,7 @@ SPECS["yolo-v1"] = [
     ("detection", {"classes": 20, "num": 3, "side": 7, "softmax": 0, "sqrt": 1}),
 ]
 
-DEFAULT_SIZE = {"mini-xnor": 32, "resnet50": 256, "densenet201": 256, "extraction": 224, "darknet-ref": 224, "tiny": 224, "alexnet": 227, "vgg-16": 256,
+DEFAULT_SIZE = {"mini-cls": 75, "mini-xnor": 32, "resnet50": 256, "densenet201": 256, "extraction": 224, "darknet-ref": 224, "tiny": 224, "alexnet": 227, "vgg-16": 256,
                 "strided": 256, "yolo-v1-small": 448, "mini-acts": 32, "yolo-v1": 448, "mini-v1-local": 40, "yolo": 416, "tiny-yolo-voc": 416, "yolo9000": 544, "darknet19": 448, "mini": 32, "mini-mfma": 64, "mini-res": 32, "tiny-yolo-v1": 448, "mini-v1": 32}
 
 

@@ -51,7 +51,8 @@ CASES = [
     ("tiny_yolo_v1_448_b1", "tiny-yolo-v1", 448, 1, 81, 0.2, 0.4, 1.0),
     ("mini_v1_local_40_b2", "mini-v1-local", 40, 2, 91, 0.2, 0.4, 1.0),
     ("mini_acts_32_b2", "mini-acts", 32, 2, 101, 0.05, 0.4, 4.0),
-    ("mini_xnor_32_b2", "mini-xnor", 32, 2, 111, 0.3, 0.4, 4.0),          # xnor=1 convolutions + standalone [batchnorm]      # the nine activations the target cfgs do not use   # [crop] [batchnorm] [local] in front of the YOLOv1 head
+    ("mini_xnor_32_b2", "mini-xnor", 32, 2, 111, 0.3, 0.4, 4.0),
+    ("mini_cls_75_b2", "mini-cls", 75, 2, 121, 0.0, 0.0, 1.0),          # classifier shapes: 7x7/2, 5x5, padded / unpadded pools, strides          # xnor=1 convolutions + standalone [batchnorm]      # the nine activations the target cfgs do not use   # [crop] [batchnorm] [local] in front of the YOLOv1 head
 ]
 
 

@@ -54,3 +54,22 @@ def test_reference_networks_match_oracle(oracle, workdir, name, crop, size, batc
     assert len(direct) <= (1 if name == "alexnet" else 0), (direct, kernels)        # alexnet's 5x5 convolution
     net.free()
     on.close()
+
+
+def test_classifier_shapes_against_reference_golden(workdir):
+    """tests/golden/mini_cls_75_b2.npz, produced by the compiled reference: 7x7/2 stem, 3x3/2 pool without padding, 5x5
+    convolution, 2x2/2 pool with padding=1, strided 3x3 and 1x1 convolutions, a shortcut, two dense layers, softmax --
+    the matrix-core path within 1e-4, the strict path bit for bit"""
+    from tests.helpers import load_golden, materialize
+    g = load_golden("mini_cls_75_b2")
+    cfg, wts, x = materialize(workdir, str(g["net"]), int(g["size"]), int(g["batch"]), int(g["seed"]), float(g["head_gain"]))
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    out = net.network_predict(x)
+    kernels = [net.layer_kernel(i) for i in range(net.n)]
+    assert kernels[0] == "conv_stem_mfma_f32" and kernels[2].endswith("_k5") and "conv_direct_f32" not in kernels, kernels
+    assert out.shape == g["out"].shape and np.abs(out - g["out"]).max() < TOL
+    assert np.array_equal(np.argsort(-out.reshape(2, -1), axis=1)[:, :3], np.argsort(-g["out"].reshape(2, -1), axis=1)[:, :3])
+    net.set_strict(True)
+    assert np.array_equal(net.network_predict(x), g["out"])
+    net.free()

@@ -7,7 +7,7 @@ import pytest
 
 from tests.helpers import dense_from_sparse, load_golden, materialize
 
-FAST = ["mini_32_b2", "mini_64_b3", "mini_mfma_64_b2", "mini_res_32_b2", "mini_v1_32_b2", "mini_v1_local_40_b2", "mini_acts_32_b2", "mini_xnor_32_b2", "tiny_yolo_v1_448_b1", "tiny_yolo_voc_416_b1", "tiny_yolo_voc_416_b1_kinect", "darknet19_224_b1"]
+FAST = ["mini_32_b2", "mini_64_b3", "mini_mfma_64_b2", "mini_res_32_b2", "mini_v1_32_b2", "mini_v1_local_40_b2", "mini_acts_32_b2", "mini_xnor_32_b2", "mini_cls_75_b2", "tiny_yolo_v1_448_b1", "tiny_yolo_voc_416_b1", "tiny_yolo_voc_416_b1_kinect", "darknet19_224_b1"]
 SLOW = ["yolo_416_b1", "yolo_608_b1", "yolo9000_96_b1", "yolo9000_96_b1_map"]
 
 
