@@ -5,20 +5,26 @@ One "step" = one pass of the hot path over one batch of synthetic frames that ar
 already resident in HBM: NCHW->NHWC, 23 convolutions (+BN/bias/leaky), 5 maxpools,
 route/reorg, region head, box decode, per-class NMS and compaction of the detections,
 ending with the small D2H copy of the compact detection records
-(y2_forward_device + y2_detect_resident of libsr_yolo2.so).
+(y2_forward_device + y2_detect_enqueue/fetch of libsr_yolo2.so).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: one process per GPU; rank 0 loads the weights, packs them into the
-kernel-layout arena and the arena is replicated with ONE RCCL broadcast
-(torch.distributed, backend "nccl"); every rank then runs its own frame batch
-(weak scaling, no per-step collective).  Timing = K steps between barriers, MAX over ranks.
+Multi-GPU: one process per GPU.  Under torchrun the ranks exist already; a bare
+`python bench.py --gpus N` starts them itself (sr_object_detection_amd/launch.py: the parent
+never touches the GPU, it spawns N fresh children with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*
+and relays rank 0's line).  Rank 0 loads the weights and packs them into the kernel-layout
+arena; ONE broadcast of that arena replicates the model -- in place on the arena pointer,
+through torch.distributed (backend "nccl" = RCCL) by default or through the library's own
+C-ABI (`--bcast c-abi`: y2_comm_init_rank + y2_broadcast_weights, RCCL called directly);
+every rank then runs its own frame batches (weak scaling, no per-step collective).
+Timing = K steps between barriers, MAX over ranks.
 
-Rank 0 prints one JSON line (see DESIGN.md section "Measurement"): value, roofline
-of the dominant kernel from HIP-event timings taken inside the timed region, and the
-CPU baseline (the reference's own CPU path compiled into oracle/_ref when present,
-otherwise the oracle port) on a bounded sample.
+Rank 0 prints one JSON line: value, roofline of the dominant kernel
+from HIP-event timings taken inside the timed region, the same loop fed from pinned host
+memory (PCIe-inclusive, never `value`), the CPU baseline (the reference's own CPU path
+compiled into oracle/_ref when present, otherwise the oracle port) and the
+detection-equivalence of the GPU and CPU paths on frames of the timed batch.
 """
 from __future__ import annotations
 
@@ -30,13 +36,9 @@ import sys
 import tempfile
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-from sr_object_detection_amd import darknet, synth, zoo  # noqa: E402
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric (608x608 fp32) is quoted on
@@ -52,17 +54,6 @@ WORKLOADS = {
     "yolo608_b32_f16": dict(net="yolo", size=608, batch=32, half=True),
 }
 
-
-def write_cfg(tmp: str, name: str, size: int, batch: int, fname: str = "net.cfg") -> str:
-    """cfg text (+ synthetic tree for yolo9000) into tmp; returns the cfg path."""
-    tree = None
-    if name == "yolo9000":
-        tree = os.path.join(tmp, "syn9k.tree")
-        if not os.path.exists(tree):
-            synth.write_tree(tree, 9418)
-    cfg = os.path.join(tmp, fname)
-    open(cfg, "w").write(zoo.cfg_text(name, size, size, batch, tree_path=tree))
-    return cfg
 PEAK_FP16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_f16: 32 cycles per 32768 FLOP per SIMD -> 16x the fp32 rate
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 THRESH, NMS = 0.2, 0.4             # Detector defaults (yolo_v2_class.hpp:45,50)
@@ -74,15 +65,37 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="yolo608_b32", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-iters", type=int, default=2, help="timed CPU-baseline forwards (0 disables the leg)")
+    ap.add_argument("--cpu-iters", type=int, default=3,
+                    help="timed CPU-baseline forwards per leg, median reported (0 disables the CPU legs)")
+    ap.add_argument("--cpu-legs", default="all", choices=["all", "headline"],
+                    help="all: tiny@416 / yolo@416 / yolo@608 at 1 thread and all cores (SURVEY 8d); headline: the workload's net, all cores")
+    ap.add_argument("--equiv-frames", type=int, default=8, help="frames of the timed batch compared with the CPU reference")
     ap.add_argument("--seed", type=int, default=31)
-    ap.add_argument("--host-input", action="store_true",
-                    help="frames start in (pageable) host memory: the PCIe-inclusive rate noted in DESIGN.md, never `value`")
+    ap.add_argument("--host-input", default="also", choices=["also", "only", "off"],
+                    help="also: after the resident loop, time the same steps fed from pinned host memory (reported as "
+                         "host_input, never as value); only: time just that; off: skip it")
+    ap.add_argument("--bcast", default=os.environ.get("Y2_BENCH_BCAST", "torch"), choices=["torch", "c-abi"],
+                    help="transport of the one weight broadcast at N>1")
+    ap.add_argument("--dump-dets", default=None, help="write each rank's last-batch detections to PATH.rank<r>.npz")
     return ap.parse_args()
+
+
+def write_cfg(tmp: str, name: str, size: int, batch: int, fname: str = "net.cfg") -> str:
+    """cfg text (+ synthetic tree for yolo9000) into tmp; returns the cfg path."""
+    from sr_object_detection_amd import synth, zoo
+    tree = None
+    if name == "yolo9000":
+        tree = os.path.join(tmp, "syn9k.tree")
+        if not os.path.exists(tree):
+            synth.write_tree(tree, 9418)
+    cfg = os.path.join(tmp, fname)
+    open(cfg, "w").write(zoo.cfg_text(name, size, size, batch, tree_path=tree))
+    return cfg
 
 
 def conv_layer_flops(net):
     """2*M*N*K per conv layer and image (src_yolo2/darknet.c:115-131), indexed by layer."""
+    from sr_object_detection_amd import darknet
     out = {}
     for i in range(net.n):
         l = net.layer(i)
@@ -93,14 +106,15 @@ def conv_layer_flops(net):
 
 def pmc_traffic(kernel: str, workload: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (counters cannot be read
-    live): profiles/r*_pmc_traffic.json, produced by tools/pmc_summary.py from separate --pmc runs of this
+    live): profiles/r*_pmc_traffic*.json, produced by tools/pmc_summary.py from separate --pmc runs of this
     same command (FETCH_SIZE doubled for gfx950, KB -> bytes).  None when no profile covers the kernel."""
-    if workload != "yolo608_b32":
-        return None
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
-            k = json.load(open(path))["kernels"].get(kernel)
+            j = json.load(open(path))
+            if j.get("workload", "yolo608_b32") != workload:
+                continue
+            k = j["kernels"].get(kernel)
             if k:
                 return int(k["hbm_bytes_per_launch"])
         except (OSError, ValueError, KeyError):
@@ -120,77 +134,188 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(cfg_b1: str, wts: str, size: int, iters: int, tmp: str):
-    """The reference CPU path on this host's cores, batch 1 (the reference's own mode), wall clock."""
-    if iters <= 0:
-        return None
-    cores = usable_cores()
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores))
-    ref_driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    t0 = time.time()
-    if os.path.exists(ref_driver):
-        try:
-            out = subprocess.run([ref_driver, "time", cfg_b1, wts, str(iters)], env=env, capture_output=True,
-                                 text=True, timeout=600, check=True).stdout.strip().splitlines()[-1]
-            r = json.loads(out)
-            return dict(value=round(1.0 / r["mean_s"], 4), unit="images/sec", cores=cores, kind="reference",
-                        sample="%d forwards of yolo.cfg %dx%d batch 1 (network_predict only, after 1 warm-up) by the "
-                               "reference's own C sources built -O2 -fopenmp; %.1f s of CPU work" % (
-                                   iters, size, size, time.time() - t0))
-        except Exception as e:      # fall through to the port
-            sys.stderr.write("cpu_baseline: reference driver failed (%s); using the oracle port\n" % e)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+REF_DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+
+
+def _cpu_leg_start(cfg_b1: str, wts: str, threads: int, iters: int):
+    """start one timing run of the reference's network_predict (1 warm-up + iters timed forwards, batch 1)"""
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
+    return subprocess.Popen([REF_DRIVER, "time", cfg_b1, wts, str(iters)], env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL, text=True)
+
+
+def _cpu_leg_port(cfg_b1: str, wts: str, size: int, threads: int, iters: int) -> dict:
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     from oracle import oracle_capi
+    from sr_object_detection_amd import synth
     on = oracle_capi.OracleNet(cfg_b1, wts)
     x = synth.image_batch(1, 3, size, size)
-    secs = on.time_predict(x, iters)
+    times = sorted(on.time_predict(x, 1) for _ in range(iters))
     on.close()
-    return dict(value=round(iters / secs, 4), unit="images/sec", cores=cores, kind="port",
-                sample="%d forwards of yolo.cfg %dx%d batch 1 (predict only, after 1 warm-up) by oracle/y2_oracle.c; "
-                       "%.1f s of CPU work" % (iters, size, size, time.time() - t0))
+    return {"median_s": times[len(times) // 2], "iters": iters}
 
 
-def map_equiv_vs_cpu(cfg_b1: str, wts: str, x0: np.ndarray, size: int, gpu_dets0: np.ndarray, tmp: str):
-    """BASELINE.json's "mAP-equiv vs CPU ref": the detections of ONE frame from the CPU reference path (decode
-    thresh/NMS as in the timed step) serve as ground truth for the GPU engine's detections of the same frame;
-    VOC AP at IoU 0.5 averaged over the classes present (sr_object_detection_amd/voc_eval.py).  1.0 = interchangeable."""
+def cpu_baseline(tmp: str, headline: dict, wts_headline: str, iters: int, legs: str, seed: int):
+    """the reference's CPU path (src_yolo2/*.c built -O2 -fopenmp by oracle/build_ref.sh; gemm.c:156 is
+    row-parallel OpenMP as is) on this host, batch 1 (the reference's own mode), network_predict only, 1 warm-up then the
+    median of `iters` forwards -- tiny-yolo-voc@416, yolo@416 and yolo@608, at 1 thread and on all usable cores.  The
+    single-thread legs run side by side (one core each) after the GPU part has finished; the all-core legs run alone.
+    The long single-thread legs take fewer iterations so that the whole CPU part stays within about a minute."""
+    if iters <= 0:
+        return None
+    from sr_object_detection_amd import synth, zoo
+    cores = usable_cores()
+    t_start = time.time()
+    kind = "reference" if os.path.exists(REF_DRIVER) else "port"
+    nets = [("tiny-yolo-voc", 416), ("yolo", 416), ("yolo", 608)] if legs == "all" else []
+    hl = (headline["net"], headline["size"])
+    if hl not in nets:
+        nets.append(hl)
+    files = {}
+    for name, size in nets:
+        cfg = write_cfg(tmp, name, size, 1, "cpu_%s_%d.cfg" % (name.replace("-", "_"), size))
+        if name == headline["net"]:
+            w = wts_headline                       # same architecture: the weight file fits every input size
+        else:
+            w = os.path.join(tmp, "cpu_%s.weights" % name.replace("-", "_"))
+            if not os.path.exists(w):
+                synth.write_weights(w, zoo.resolve(name, size), seed)
+        files[(name, size)] = (cfg, w)
+    gflop = {k: zoo.conv_flops(zoo.resolve(k[0], k[1])) / 1e9 for k in nets}
+    rows = []
+
+    def finish(p):
+        out = p.communicate(timeout=900)[0].strip().splitlines()[-1]
+        return json.loads(out)
+
+    if kind == "reference":
+        try:
+            single = []
+            if legs == "all":
+                for k in nets:          # 1 thread: about 0.25 GFLOP/s-per-GFLOP ... budget the long ones
+                    it = iters if gflop[k] < 40 else 1
+                    single.append((k, it, _cpu_leg_start(*files[k], threads=1, iters=it)))
+            for k, it, p in single:
+                r = finish(p)
+                rows.append(dict(config="%s.cfg %dx%d b1" % (k[0], k[1], k[1]), threads=1, iters=it,
+                                 median_s=round(r["median_s"], 4), images_per_sec=round(1.0 / r["median_s"], 4)))
+            for k in nets:
+                r = finish(_cpu_leg_start(*files[k], threads=cores, iters=iters))
+                rows.append(dict(config="%s.cfg %dx%d b1" % (k[0], k[1], k[1]), threads=cores, iters=iters,
+                                 median_s=round(r["median_s"], 4), images_per_sec=round(1.0 / r["median_s"], 4)))
+        except Exception as e:      # fall through to the port
+            sys.stderr.write("cpu_baseline: reference driver failed (%s); using the oracle port\n" % e)
+            kind, rows = "port", []
+    if kind == "port":
+        for k in nets:
+            for threads in ([1, cores] if legs == "all" else [cores]):
+                it = iters if (threads > 1 or gflop[k] < 40) else 1
+                r = _cpu_leg_port(*files[k], size=k[1], threads=threads, iters=it)
+                rows.append(dict(config="%s.cfg %dx%d b1" % (k[0], k[1], k[1]), threads=threads, iters=it,
+                                 median_s=round(r["median_s"], 4), images_per_sec=round(1.0 / r["median_s"], 4)))
+    head = next(r for r in rows if r["config"].startswith("%s.cfg %dx" % hl) and r["threads"] == cores)
+    return dict(value=head["images_per_sec"], unit="images/sec", cores=cores, kind=kind,
+                sample="median of %d forwards (after 1 warm-up) of %s batch 1, network_predict only, by %s; all legs "
+                       "together %.0f s of wall time" % (
+                           head["iters"], head["config"],
+                           "the reference's own C sources built -O2 -fopenmp" if kind == "reference" else "oracle/y2_oracle.c",
+                           time.time() - t_start),
+                cpu_model=cpu_model(), legs=rows)
+
+
+def equivalence_vs_cpu(tmp: str, name: str, size: int, wts: str, x, gpu_dets, nframes: int):
+    """BASELINE.json's "mAP-equiv vs CPU ref" over `nframes` frames of the timed batch: the CPU reference path's
+    detections (same decode thresh / NMS as the timed step) against the GPU engine's for the same frames --
+    identical post-NMS counts, identical classes, box / probability differences (the 1e-4 bar of north_star), and
+    VOC AP at IoU 0.5 with the CPU detections as ground truth (sr_object_detection_amd/voc_eval.py; 1.0 =
+    interchangeable).  Random frames and weights carry no decision margin, so a probability within ~2e-5 of the
+    threshold may legitimately flip; flips are reported, not hidden."""
+    import numpy as np
     from sr_object_detection_amd import voc_eval
-    ref_driver = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    nframes = max(1, min(nframes, len(gpu_dets)))
     kind = "reference"
+    boxes_all, post_all = [], []
     try:
-        if not os.path.exists(ref_driver):
-            raise FileNotFoundError(ref_driver)
-        inp = os.path.join(tmp, "frame0.bin")
-        np.ascontiguousarray(x0, dtype=np.float32).tofile(inp)
-        out_dir = os.path.join(tmp, "ref0")
+        if not os.path.exists(REF_DRIVER):
+            raise FileNotFoundError(REF_DRIVER)
+        cfg_n = write_cfg(tmp, name, size, nframes, "equiv_b%d.cfg" % nframes)
+        inp = os.path.join(tmp, "equiv_frames.bin")
+        np.ascontiguousarray(x[:nframes], dtype=np.float32).tofile(inp)
+        out_dir = os.path.join(tmp, "equiv_ref")
         os.makedirs(out_dir, exist_ok=True)
         env = dict(os.environ, OMP_NUM_THREADS=str(usable_cores()))
-        subprocess.run([ref_driver, "net", cfg_b1, wts, inp, out_dir, repr(THRESH), repr(NMS), "0"], env=env,
-                       capture_output=True, timeout=600, check=True)
-        boxes = np.fromfile(os.path.join(out_dir, "boxes_0.bin"), dtype=np.float32).reshape(-1, 4)
-        post = np.fromfile(os.path.join(out_dir, "probs_post_0.bin"), dtype=np.float32).reshape(len(boxes), -1)
+        subprocess.run([REF_DRIVER, "net", cfg_n, wts, inp, out_dir, repr(THRESH), repr(NMS), "0"], env=env,
+                       capture_output=True, timeout=900, check=True)
+        for b in range(nframes):
+            boxes = np.fromfile(os.path.join(out_dir, "boxes_%d.bin" % b), dtype=np.float32).reshape(-1, 4)
+            post = np.fromfile(os.path.join(out_dir, "probs_post_%d.bin" % b), dtype=np.float32).reshape(len(boxes), -1)
+            boxes_all.append(boxes)
+            post_all.append(post)
     except Exception as e:
-        sys.stderr.write("map_equiv: reference driver unavailable (%s); using the oracle port\n" % e)
+        sys.stderr.write("equivalence: reference driver unavailable (%s); using the oracle port\n" % e)
         kind = "port"
         from oracle import oracle_capi
+        cfg_b1 = write_cfg(tmp, name, size, 1, "equiv_b1.cfg")
         on = oracle_capi.OracleNet(cfg_b1, wts)
-        on.predict(x0[None])
-        boxes, probs = on.region_boxes(0, THRESH)
-        post = oracle_capi.do_nms_sort(boxes, probs, NMS)
+        boxes_all, post_all = [], []
+        for b in range(nframes):
+            on.predict(x[b][None])
+            boxes, probs = on.region_boxes(0, THRESH)
+            boxes_all.append(boxes)
+            post_all.append(oracle_capi.do_nms_sort(boxes, probs, NMS))
         on.close()
-    ref_rows = voc_eval.detections_from_dense(boxes, post, THRESH, size, size)
-    cand = [(int(d["obj_id"]), float(d["prob"]), (d["x"] - d["w"] / 2) * size, (d["y"] - d["h"] / 2) * size,
-             (d["x"] + d["w"] / 2) * size, (d["y"] + d["h"] / 2) * size) for d in gpu_dets0]
-    m, n_ref = voc_eval.map_equiv_rows({"frame0": cand}, {"frame0": ref_rows})
-    return dict(value=None if np.isnan(m) else round(m, 4), iou=0.5, frames=1, cpu_detections=n_ref, gpu_detections=len(cand), kind=kind)
+    ref_rows, cand_rows = {}, {}
+    n_ref = n_gpu = 0
+    counts_equal = True
+    max_box = max_prob = 0.0
+    mismatched = []
+    for b in range(nframes):
+        boxes, post = boxes_all[b], post_all[b]
+        key = "frame%d" % b
+        ref_rows[key] = voc_eval.detections_from_dense(boxes, post, THRESH, size, size)
+        d = gpu_dets[b]
+        cand_rows[key] = [(int(r["obj_id"]), float(r["prob"]), (r["x"] - r["w"] / 2) * size, (r["y"] - r["h"] / 2) * size,
+                           (r["x"] + r["w"] / 2) * size, (r["y"] + r["h"] / 2) * size) for r in d]
+        keep = np.nonzero(post.max(axis=1) > THRESH)[0]          # ascending box order, as y2_detect collects
+        n_ref += keep.size
+        n_gpu += len(d)
+        if keep.size != len(d) or not np.array_equal(post[keep].argmax(axis=1), d["obj_id"]):
+            counts_equal = counts_equal and keep.size == len(d)
+            mismatched.append(b)
+            continue
+        if keep.size:
+            got = np.stack([d["x"], d["y"], d["w"], d["h"]], 1)
+            want = boxes[keep]
+            max_box = max(max_box, float((np.abs(got - want) / np.maximum(1.0, np.abs(want))).max()))
+            max_prob = max(max_prob, float(np.abs(d["prob"] - post[keep].max(axis=1)).max()))
+    m, _ = voc_eval.map_equiv_rows(cand_rows, ref_rows)
+    return dict(value=None if np.isnan(m) else round(m, 4), iou=0.5, frames=nframes, cpu_detections=n_ref, gpu_detections=n_gpu,
+                post_nms_counts_equal=bool(counts_equal), frames_with_a_different_set=mismatched,
+                max_abs_box_err=max_box, max_abs_prob_err=max_prob, tolerance=1e-4, kind=kind)
 
 
 def main():
     args = parse_args()
+    # Become the launcher before anything can touch the GPU (no torch, no libsr_yolo2.so in this process yet).
+    from sr_object_detection_amd import launch
+    launch.self_launch_if_needed(args.gpus)
+
+    import numpy as np
+    from sr_object_detection_amd import darknet, synth, zoo
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         sys.stderr.write("bench: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
     import torch
     if not torch.cuda.is_available():
@@ -198,7 +323,11 @@ def main():
     # Y2_BENCH_BACKEND=gloo + Y2_BENCH_SHARE_GPU=1 rehearse the N>1 path on a box with ONE GPU (all ranks on
     # cuda:0, broadcast staged through the host); the real multi-GPU run uses nccl (= RCCL), one GPU per rank.
     backend = os.environ.get("Y2_BENCH_BACKEND", "nccl")
-    device_index = local_rank % torch.cuda.device_count() if os.environ.get("Y2_BENCH_SHARE_GPU") else local_rank
+    share = bool(os.environ.get("Y2_BENCH_SHARE_GPU"))
+    ndev = torch.cuda.device_count()
+    if world > ndev and not share:
+        sys.exit("bench: %d ranks but only %d GPU(s) visible (one process per GPU; Y2_BENCH_SHARE_GPU=1 rehearses on one)" % (world, ndev))
+    device_index = local_rank % ndev if share else local_rank
     torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
@@ -226,23 +355,62 @@ def main():
         synth.write_weights(wts, layers, args.seed)
         net.load_weights(wts)
         net.prepare()
-    arena_ptr, arena_bytes = net.weights_arena()
+    bcast_how, bcast_ms = "none (1 rank)", None
     if world > 1:
-        # replicate the packed weights: ONE broadcast of the kernel-layout arena over RCCL/xGMI
-        on_gpu = backend == "nccl"
-        buf = torch.empty(arena_bytes, dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
-        to_buf = L.y2h_memcpy_d2d if on_gpu else L.y2h_memcpy_d2h
-        from_buf = L.y2h_memcpy_d2d if on_gpu else L.y2h_memcpy_h2d
-        if rank == 0:
-            assert to_buf(buf.data_ptr(), arena_ptr, arena_bytes, None) == 0
-            L.y2h_device_sync()
-        dist.broadcast(buf, src=0)
+        # replicate the packed weights: ONE broadcast of the kernel-layout arena, in place on the arena pointer
+        arena_ptr, arena_bytes = net.weights_arena()
         torch.cuda.synchronize()
-        if rank != 0:
-            assert from_buf(arena_ptr, buf.data_ptr(), arena_bytes, None) == 0
-            L.y2h_device_sync()
-            net.weights_resident()
-        del buf
+        if dist is not None:
+            dist.barrier()
+        tb = time.perf_counter()
+        if args.bcast == "c-abi" and backend == "nccl":
+            # RCCL through the library's own C-ABI (include/sr_yolo2.h): the 128-byte unique id travels over the
+            # process group's store, the collective runs on the arena pointer on the engine's stream
+            uid = [darknet.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = darknet.comm_init_rank(world, uid[0], rank, device_index)
+            net.broadcast_weights(comm, 0)
+            darknet.comm_destroy(comm)
+            bcast_how = "RCCL ncclBroadcast via the C-ABI (y2_broadcast_weights, %s), in place on the arena" % darknet.comm_library()
+        elif backend == "nccl":
+            class _Arena:          # zero-copy view of the arena for torch (no D2D bounce)
+                __cuda_array_interface__ = {"shape": (arena_bytes,), "typestr": "|u1", "data": (arena_ptr, False), "version": 2}
+            try:
+                view = torch.as_tensor(_Arena(), device=torch.device("cuda", device_index))
+                assert view.data_ptr() == arena_ptr and view.numel() == arena_bytes
+                dist.broadcast(view, src=0)
+                torch.cuda.synchronize()
+                del view
+                bcast_how = "torch.distributed broadcast (nccl = RCCL), in place on the arena pointer"
+            except (AssertionError, TypeError, RuntimeError) as e:
+                sys.stderr.write("bench: zero-copy arena view unavailable (%s); staging through a torch tensor\n" % e)
+                buf = torch.empty(arena_bytes, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    assert L.y2h_memcpy_d2d(buf.data_ptr(), arena_ptr, arena_bytes, None) == 0
+                    L.y2h_device_sync()
+                dist.broadcast(buf, src=0)
+                torch.cuda.synchronize()
+                if rank != 0:
+                    assert L.y2h_memcpy_d2d(arena_ptr, buf.data_ptr(), arena_bytes, None) == 0
+                    L.y2h_device_sync()
+                del buf
+                bcast_how = "torch.distributed broadcast (nccl = RCCL) through a staging tensor"
+            if rank != 0:
+                net.weights_resident()
+        else:
+            buf = torch.empty(arena_bytes, dtype=torch.uint8, device="cpu")
+            if rank == 0:
+                assert L.y2h_memcpy_d2h(buf.data_ptr(), arena_ptr, arena_bytes, None) == 0
+                L.y2h_device_sync()
+            dist.broadcast(buf, src=0)
+            if rank != 0:
+                assert L.y2h_memcpy_h2d(arena_ptr, buf.data_ptr(), arena_bytes, None) == 0
+                L.y2h_device_sync()
+                net.weights_resident()
+            del buf
+            bcast_how = "%s broadcast staged through host memory (one-GPU rehearsal)" % backend
+        torch.cuda.synchronize()
+        bcast_ms = round((time.perf_counter() - tb) * 1e3, 2)
 
     # this rank's frames: global image index = rank*batch + i, resident in HBM before timing starts
     x = synth.image_batch(batch, 3, size, size, seed=0xC0FFEE + rank * batch)
@@ -251,13 +419,19 @@ def main():
 
     is_detector = darknet.LAYER_TYPES[net.last.type] == "REGION"
 
+    def enqueue_results():
+        if is_detector:
+            net.detect_enqueue(THRESH, NMS)
+        else:
+            net.output_enqueue()
+
+    def fetch_results():
+        return net.detect_fetch() if is_detector else (net.output_fetch(), np.zeros(1))
+
     def step():
-        if not is_detector:                 # classifier: forward + host copy of the class scores
-            return net.predict_device(d_x.data_ptr()), np.zeros(1)
-        if args.host_input:
-            return net.detect(x, THRESH, NMS)
         net.forward_device(d_x.data_ptr())
-        return net.detect_resident(THRESH, NMS)
+        enqueue_results()
+        return fetch_results()
 
     for _ in range(args.warmup):
         dets, counts = step()
@@ -286,42 +460,108 @@ def main():
                 per_kernel_flops[k] = per_kernel_flops.get(k, 0.0) + flops[i] * batch
                 per_kernel_launches[k] = per_kernel_launches.get(k, 0) + 1
 
-    pipelined = not args.host_input and not os.environ.get("Y2_BENCH_NO_PIPELINE")
-    barrier()
-    t0 = time.perf_counter()
-    if pipelined:
-        # Every step is still one forward + one decode/NMS/collect + one fetch of the detections; the host side of step
-        # i (waiting for its records, unpacking them) overlaps the device side of step i+1: y2_detect_fetch waits for an
-        # event behind step i's D2H copies only, so the next forward is already queued when the host blocks.
-        # (a classifier's step is forward + host copy of the class scores: y2_output_enqueue / y2_output_fetch.)
-        def enqueue_results():
-            if is_detector:
-                net.detect_enqueue(THRESH, NMS)
-            else:
-                net.output_enqueue()
-
-        def fetch_results():
-            return net.detect_fetch() if is_detector else (net.output_fetch(), np.zeros(1))
-
-        net.forward_device(d_x.data_ptr())
+    def timed_loop(forward, account):
+        """K steps between barriers.  Every step is one forward + one decode/NMS/collect + one fetch of the detections;
+        the host side of step i (waiting for its records, unpacking them) overlaps the device side of step i+1:
+        y2_detect_fetch waits for an event behind step i's D2H copies only, so the next forward is already queued when the
+        host blocks.  (A classifier's step is forward + host copy of the class scores: y2_output_enqueue / _fetch.)"""
+        res = (None, None)
+        barrier()
+        t0 = time.perf_counter()
+        forward(0)
         enqueue_results()
-        for _ in range(args.steps - 1):
-            account_layer_times()                       # needs the previous forward's events, not its results
-            net.forward_device(d_x.data_ptr())
-            dets, counts = fetch_results()
+        for i in range(1, args.steps):
+            if account:
+                account_layer_times()                   # needs the previous forward's events, not its results
+            forward(i)
+            res = fetch_results()
             enqueue_results()
-        account_layer_times()
-        dets, counts = fetch_results()
-    else:
-        for _ in range(args.steps):
-            dets, counts = step()
+        if account:
             account_layer_times()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        res = fetch_results()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, res
+
+    elapsed = None
+    if args.host_input != "only":
+        elapsed, (dets, counts) = timed_loop(lambda i: net.forward_device(d_x.data_ptr()), True)
+
+    host = None
+    if args.host_input != "off":
+        # The same K steps with every batch starting in HOST memory: two pinned slots, the upload of batch i+1 on the copy
+        # stream while batch i computes (y2_feed_*).  Two producers are timed: frames that already sit in the pinned slots
+        # (a capture library / decoder that writes straight into them) and frames in pageable memory that a producer thread
+        # copies into the slot first (141 MB per fp32 batch of 32 608x608 frames), as a camera thread would.
+        import queue
+        import threading
+        net.set_timing(False)
+        net.feed_open(2)
+        slots = [net.feed_host(s) for s in range(2)]
+        flat = x.reshape(-1)
+
+        def run_fed(pageable: bool):
+            if not pageable:
+                for s_ in range(2):
+                    slots[s_][:flat.size] = flat
+
+                def forward(i):
+                    if i == 0:
+                        net.feed_submit(0)
+                    net.feed_forward(i & 1)
+                    if i + 1 < args.steps:
+                        net.feed_submit((i + 1) & 1)    # waits ON THE DEVICE for the forward that last read that slot
+                return timed_loop(forward, False)
+            ready = queue.Queue()
+            submitted = [threading.Semaphore(1), threading.Semaphore(1)]
+
+            def producer():
+                for k in range(args.steps):
+                    s_ = k & 1
+                    submitted[s_].acquire()             # batch k-2's upload has been submitted ...
+                    net.feed_wait_host(s_)              # ... and has left the pinned buffer
+                    slots[s_][:flat.size] = flat        # numpy releases the GIL for this copy
+                    ready.put(k)
+
+            th = threading.Thread(target=producer, daemon=True)
+
+            def forward(i):
+                if i == 0:
+                    th.start()
+                assert ready.get(timeout=120) == i
+                net.feed_submit(i & 1)
+                submitted[i & 1].release()
+                net.feed_forward(i & 1)
+            out = timed_loop(forward, False)
+            th.join(timeout=120)
+            return out
+
+        keep_steps = args.steps
+        args.steps = 2                                   # warm the path (copy stream, first-touch of the pinned pages)
+        run_fed(False)
+        args.steps = keep_steps
+        p_el, p_res = run_fed(False)
+        g_el, g_res = run_fed(True)
+        net.feed_close()
+        img = world * batch * args.steps
+        host = dict(value=round(img / p_el, 2), unit="images/sec", ms_per_step=round(p_el / args.steps * 1e3, 3),
+                    source="pinned host slots (2), async H2D of batch i+1 on a copy stream under batch i's forward; %.0f MB "
+                           "cross PCIe per batch" % (flat.nbytes / 1e6),
+                    pageable_source=dict(value=round(img / g_el, 2), ms_per_step=round(g_el / args.steps * 1e3, 3),
+                                         note="a producer thread first copies each batch from pageable memory into the pinned slot"))
+        if elapsed is None:
+            elapsed, (dets, counts) = p_el, p_res
+        else:
+            host["fraction_of_resident"] = round(host["value"] / (img / elapsed), 4)
+            host["pageable_source"]["fraction_of_resident"] = round(host["pageable_source"]["value"] / (img / elapsed), 4)
+
+    if args.dump_dets and is_detector:
+        np.savez(args.dump_dets + ".rank%d.npz" % rank, counts=np.asarray(counts),
+                 **{"dets_%d" % b: dets[b] for b in range(len(dets))})
 
     if rank == 0:
         total_images = world * batch * args.steps
@@ -335,28 +575,31 @@ def main():
                         avg_launch_ms=round(per_kernel_ms[dom] / per_kernel_launches[dom], 4),
                         avg_launch_gflop=round(per_kernel_flops[dom] / per_kernel_launches[dom] / 1e9, 3))
         conv_ms = sum(per_kernel_ms.values()) / max(args.steps, 1)
-        cfg_b1 = write_cfg(tmp, name, size, 1, "net_b1.cfg")
-        # the CPU leg is timed at N=1 only (rank 0 would otherwise hold the other ranks at the final barrier)
-        cpu = cpu_baseline(cfg_b1, wts, size, args.cpu_iters, tmp) if world == 1 else None
-        mapeq = None
-        if world == 1 and args.cpu_iters > 0 and is_detector and not args.host_input:
-            mapeq = map_equiv_vs_cpu(cfg_b1, wts, x[0], size, dets[0], tmp)
+        conv_flops_step = sum(per_kernel_flops.values()) / max(args.steps, 1)
+        # the CPU legs are timed at N=1 only (rank 0 would otherwise hold the other ranks at the final barrier)
+        cpu = cpu_baseline(tmp, wl, wts, args.cpu_iters, args.cpu_legs, args.seed) if world == 1 else None
+        equiv = None
+        if world == 1 and args.cpu_iters > 0 and is_detector and args.equiv_frames > 0:
+            equiv = equivalence_vs_cpu(tmp, name, size, wts, x, dets, args.equiv_frames)
+        what = ("forward + region decode + NMS(%.1f) + collect + fetch of the detections" % NMS) if is_detector else \
+               "forward (conv trunk, avgpool, softmax) + fetch of the class scores"
         line = {
-            "metric": "images/sec YOLOv2 608x608 fp32" if (size == 608 and not half) else
+            "metric": "images/sec YOLOv2 608x608 fp32" if (name == "yolo" and size == 608 and not half) else
                       "images/sec %s %dx%d %s" % (name, size, size, "fp16" if half else "fp32"),
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if half else "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d batch %d per GPU: forward + region decode + NMS(%.1f) + collect, "
-                                   "%s" % (name + ".cfg", size, size, batch, NMS,
-                                                   "inputs in host memory (PCIe-inclusive)" if args.host_input
-                                                   else "inputs resident in HBM"),
-                       "global_batch": batch * world, "parallelism": "frame-sharded x%d (RCCL weight broadcast)" % world,
+            "config": {"workload": "%s %dx%d batch %d per GPU: %s, %s" % (
+                           name + ".cfg", size, size, batch, what,
+                           "inputs in pinned host memory (PCIe-inclusive)" if args.host_input == "only" else "inputs resident in HBM"),
+                       "global_batch": batch * world, "parallelism": "frame-sharded x%d (one weight broadcast)" % world,
+                       "weight_broadcast": bcast_how, "weight_broadcast_ms": bcast_ms,
                        "gflop_per_image": round(zoo.conv_flops(layers) / 1e9, 3),
                        "conv_ms_per_step": round(conv_ms, 3),
-                       "host_fetch_overlaps_next_forward": bool(pipelined),
+                       "conv_tflops": round(conv_flops_step / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
+                       "host_fetch_overlaps_next_forward": True,
                        "detections_in_last_batch": int(np.sum(counts))},
-            "roofline": roof, "cpu_baseline": cpu, "map_equiv_vs_cpu": mapeq,
+            "roofline": roof, "cpu_baseline": cpu, "host_input": host, "map_equiv_vs_cpu": equiv,
             "kernels_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in sorted(per_kernel_ms.items())},
             "device": darknet.device_name(),
         }

@@ -284,6 +284,33 @@ void y2_set_half(network *net, int on);
 /* Declare the arena contents valid although load_weights was not called on this process
  * (e.g. it was filled by an RCCL broadcast from rank 0). */
 void y2_weights_resident(network *net);
+/* Multi-GPU (one process per GPU, frames sharded): replicate root's packed weights with ONE in-place RCCL broadcast of
+ * the arena over xGMI -- replaces the host-staged distribute_weights of network_kernels.cu:240-250.  `comm` is an
+ * ncclComm_t of the RCCL this process uses (y2_comm_library() names it); the three y2_comm_* helpers create one
+ * without any other dependency: rank 0 calls y2_comm_unique_id and hands the 128 bytes to the other ranks by whatever
+ * channel the launcher has (a file, a socket, an env variable), then every rank calls y2_comm_init_rank.  Root must
+ * have called load_weights; the other ranks only parse the cfg.  Returns 0 or <0 (y2_last_error()). */
+#define Y2_COMM_ID_BYTES 128
+const char *y2_comm_library(void);
+int y2_comm_unique_id(void *id_out);
+int y2_comm_init_rank(void **comm, int nranks, const void *id, int rank, int device);
+int y2_comm_destroy(void *comm);
+int y2_broadcast_weights(network *net, void *comm, int root);
+/* Pinned, multi-buffered host feed (replaces the per-call cudaMalloc + pageable H2D + cudaFree of
+ * network_kernels.cu:392-405): `slots` pairs of (pinned host buffer, HBM buffer) of slot_bytes each (0 = one batch of
+ * float NCHW frames) and a copy stream.  The producer writes a batch into y2_feed_host(net, s), y2_feed_submit starts
+ * its upload, y2_feed_forward / y2_feed_forward_u8 (camera frames [batch][h][step] bytes, as y2_ingest_u8) make the
+ * forward wait ON THE DEVICE for that upload -- so batch i+1 crosses PCIe while batch i computes.  Follow with
+ * y2_detect_enqueue / y2_detect_fetch.  y2_feed_wait_host blocks until a slot's pinned buffer may be overwritten. */
+int y2_feed_open(network *net, int slots, size_t slot_bytes);
+void y2_feed_close(network *net);
+void *y2_feed_host(network net, int slot);
+void *y2_feed_device(network net, int slot);
+size_t y2_feed_slot_bytes(network net);
+int y2_feed_submit(network net, int slot, size_t bytes);
+int y2_feed_wait_host(network net, int slot);
+int y2_feed_forward(network net, int slot);
+int y2_feed_forward_u8(network net, int slot, int h, int w, int c, int step, int swap_rb, int letterbox);
 /* network_predict with the input already in HBM (NCHW, batch*inputs floats).  The returned
  * pointer is the same host buffer network_predict returns. */
 float *y2_network_predict_device(network net, const float *d_input);

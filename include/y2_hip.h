@@ -80,6 +80,7 @@ int         y2h_event_create(y2h_event *e);
 int         y2h_event_destroy(y2h_event e);
 int         y2h_event_record(y2h_event e, y2h_stream s);
 int         y2h_event_sync(y2h_event e);                                        /* wait for the event only */
+int         y2h_stream_wait_event(y2h_stream s, y2h_event e);                    /* later work on s runs after e (device-side wait) */
 int         y2h_event_elapsed_ms(y2h_event start, y2h_event stop, float *ms);   /* syncs on stop */
 
 /* ---- hipGraph capture of a kernel sequence on a stream (replaces nothing in the reference: its GPU path launches

@@ -184,15 +184,22 @@ static int cmd_time(int argc, char **argv)
     float *X = malloc(n * sizeof(float));
     for (j = 0; j < n; ++j) X[j] = (float)((j * 2654435761u) % 1000) / 1000.f;
     network_predict(net, X); /* warm-up */
-    double best = 1e30, sum = 0;
+    double best = 1e30, sum = 0, med;
+    double *ts = calloc(iters > 0 ? iters : 1, sizeof(double));
+    int k;
     for (i = 0; i < iters; ++i) {
         double t0 = now_s();
         network_predict(net, X);
         double dt = now_s() - t0;
         if (dt < best) best = dt;
         sum += dt;
+        for (k = i; k > 0 && ts[k - 1] > dt; --k) ts[k] = ts[k - 1];     /* keep sorted */
+        ts[k] = dt;
     }
-    printf("{\"batch\": %d, \"iters\": %d, \"mean_s\": %.6f, \"best_s\": %.6f}\n", net.batch, iters, sum / iters, best);
+    med = iters > 0 ? ((iters & 1) ? ts[iters / 2] : 0.5 * (ts[iters / 2 - 1] + ts[iters / 2])) : 0;
+    printf("{\"batch\": %d, \"iters\": %d, \"mean_s\": %.6f, \"best_s\": %.6f, \"median_s\": %.6f}\n", net.batch, iters,
+           sum / iters, best, med);
+    free(ts);
     return 0;
 }
 

@@ -11,9 +11,9 @@
  * + parser.c:450-489; reorg_layer.c:7-43; region_layer.c:14-51 + parser.c:236-285;
  * avgpool_layer.c:5-31; softmax_layer.c:10-33; cost_layer.c:32-55).
  *
- * Only the seven layer types on the YOLOv2 / Darknet-19 forward path are
- * built ([convolutional] [maxpool] [route] [reorg] [region] [avgpool]
- * [softmax], plus [cost] which does nothing at inference); any other section
+ * Sections built: the YOLOv2 / Darknet-19 forward path ([convolutional] [maxpool] [route] [reorg] [region] [avgpool]
+ * [softmax], [cost] which does nothing at inference) plus the heads SURVEY 8(f)-4 admits ([shortcut], the YOLOv1
+ * head [connected] [dropout] [detection]) and [crop] [local] [batchnorm]; any other section ([rnn], [gru], ...)
  * is an error rather than a silent skip.  No device memory is touched here:
  * HBM buffers are planned at the first predict (y2_engine.c).
  */

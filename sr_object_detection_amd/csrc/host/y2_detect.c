@@ -18,6 +18,8 @@
 #include "y2_internal.h"
 
 #define HIPCALL(expr) do { int rc_ = (expr); if (rc_ != 0) { y2_fail("%s failed (%d): %s", #expr, rc_, y2h_last_error()); return; } } while (0)
+/* inside functions that own scratch buffers: report, then release them at `cleanup:` */
+#define HIPCALL_C(expr) do { int rc_ = (expr); if (rc_ != 0) { y2_fail("%s failed (%d): %s", #expr, rc_, y2h_last_error()); goto cleanup; } } while (0)
 #define HIPCALL_I(expr) do { int rc_ = (expr); if (rc_ != 0) { y2_fail("%s failed (%d): %s", #expr, rc_, y2h_last_error()); return -1; } } while (0)
 
 static y2_ldev *ld_of(const layer *l) { return (y2_ldev *)l->dev; }
@@ -32,7 +34,7 @@ void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *b
     y2h_decode q;
     int total = l.w * l.h * l.n, i;
     size_t pred_floats = (size_t)total * (l.classes + 5);
-    float *d_pred, *d_tmp_pred = NULL, *h_probs;
+    float *d_pred, *d_tmp_pred = NULL, *h_probs = NULL;
     int *d_tmp_map = NULL;
     if (l.type != REGION || !d || !d->eng || !d->eng->built) { y2_fail("get_region_boxes: layer is not a prepared region layer"); return; }
     if (!l.output) { y2_fail("get_region_boxes: l.output is NULL"); return; }
@@ -47,32 +49,33 @@ void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *b
     if (l.output >= e->h_out && l.output < e->h_out + e->out_floats && (size_t)(l.output - e->h_out) % l.outputs == 0) {
         d_pred = d->d_region + (l.output - e->h_out);           /* batch item (l.output - h_out)/outputs */
     } else {
-        HIPCALL(y2h_malloc((void **)&d_tmp_pred, pred_floats * sizeof(float)));
-        HIPCALL(y2h_memcpy_h2d(d_tmp_pred, l.output, pred_floats * sizeof(float), e->stream));
+        HIPCALL_C(y2h_malloc((void **)&d_tmp_pred, pred_floats * sizeof(float)));
+        HIPCALL_C(y2h_memcpy_h2d(d_tmp_pred, l.output, pred_floats * sizeof(float), e->stream));
         d_pred = d_tmp_pred;
     }
     if (map && l.softmax_tree) {
         if (map == l.map && d->d_map) q.map = d->d_map;
         else {
-            HIPCALL(y2h_malloc((void **)&d_tmp_map, 200 * sizeof(int)));
-            HIPCALL(y2h_memcpy_h2d(d_tmp_map, map, 200 * sizeof(int), e->stream));
+            HIPCALL_C(y2h_malloc((void **)&d_tmp_map, 200 * sizeof(int)));
+            HIPCALL_C(y2h_memcpy_h2d(d_tmp_map, map, 200 * sizeof(int), e->stream));
             q.map = d_tmp_map;
         }
     }
     q.pred = d_pred; q.boxes = e->d_boxes; q.probs = e->d_probs;
-    if (q.map) HIPCALL(y2h_memset(e->d_probs, 0, (size_t)total * l.classes * sizeof(float), e->stream));
-    HIPCALL(y2h_region_boxes(&q, e->stream));
+    if (q.map) HIPCALL_C(y2h_memset(e->d_probs, 0, (size_t)total * l.classes * sizeof(float), e->stream));
+    HIPCALL_C(y2h_region_boxes(&q, e->stream));
     h_probs = malloc((size_t)total * l.classes * sizeof(float));
-    HIPCALL(y2h_memcpy_d2h(boxes, e->d_boxes, (size_t)total * sizeof(box), e->stream));
-    HIPCALL(y2h_memcpy_d2h(h_probs, e->d_probs, (size_t)total * l.classes * sizeof(float), e->stream));
+    HIPCALL_C(y2h_memcpy_d2h(boxes, e->d_boxes, (size_t)total * sizeof(box), e->stream));
+    HIPCALL_C(y2h_memcpy_d2h(h_probs, e->d_probs, (size_t)total * l.classes * sizeof(float), e->stream));
     if (l.softmax_tree)      /* the reference rewrites the class scores in l.output in place (region_layer.c:350) */
-        HIPCALL(y2h_memcpy_d2h(l.output, d_pred, pred_floats * sizeof(float), e->stream));
-    HIPCALL(y2h_stream_sync(e->stream));
+        HIPCALL_C(y2h_memcpy_d2h(l.output, d_pred, pred_floats * sizeof(float), e->stream));
+    HIPCALL_C(y2h_stream_sync(e->stream));
     {
         int ncopy = (q.map) ? 200 : l.classes;               /* with a map only 200 entries per row are written */
         for (i = 0; i < total; ++i) memcpy(probs[i], h_probs + (size_t)i * l.classes, ncopy * sizeof(float));
         if (q.map && only_objectness) for (i = 0; i < total; ++i) probs[i][0] = h_probs[(size_t)i * l.classes];
     }
+cleanup:
     free(h_probs);
     y2h_free(d_tmp_pred);
     y2h_free(d_tmp_map);
@@ -85,7 +88,7 @@ void get_detection_boxes(layer l, int w, int h, float thresh, float **probs, box
     y2_ldev *d = ld_of(&l);
     y2_engine *e;
     int total = l.side * l.side * l.n, i;
-    float *d_pred, *d_tmp = NULL, *h_probs;
+    float *d_pred, *d_tmp = NULL, *h_probs = NULL;
     if (l.type != DETECTION || !d || !d->eng || !d->eng->built) { y2_fail("get_detection_boxes: layer is not a prepared detection layer"); return; }
     if (!l.output) { y2_fail("get_detection_boxes: l.output is NULL"); return; }
     e = d->eng;
@@ -94,17 +97,18 @@ void get_detection_boxes(layer l, int w, int h, float thresh, float **probs, box
     if (l.output >= e->h_out && l.output < e->h_out + e->out_floats && (size_t)(l.output - e->h_out) % l.outputs == 0)
         d_pred = d->d_flat + (l.output - e->h_out);
     else {
-        HIPCALL(y2h_malloc((void **)&d_tmp, (size_t)l.outputs * sizeof(float)));
-        HIPCALL(y2h_memcpy_h2d(d_tmp, l.output, (size_t)l.outputs * sizeof(float), e->stream));
+        HIPCALL_C(y2h_malloc((void **)&d_tmp, (size_t)l.outputs * sizeof(float)));
+        HIPCALL_C(y2h_memcpy_h2d(d_tmp, l.output, (size_t)l.outputs * sizeof(float), e->stream));
         d_pred = d_tmp;
     }
-    HIPCALL(y2h_detection_boxes(d_pred, (long)l.outputs, 1, l.side, l.n, l.classes, l.sqrt, w, h, thresh, only_objectness,
+    HIPCALL_C(y2h_detection_boxes(d_pred, (long)l.outputs, 1, l.side, l.n, l.classes, l.sqrt, w, h, thresh, only_objectness,
                                 e->d_boxes, e->d_probs, e->stream));
     h_probs = malloc((size_t)total * l.classes * sizeof(float));
-    HIPCALL(y2h_memcpy_d2h(boxes, e->d_boxes, (size_t)total * sizeof(box), e->stream));
-    HIPCALL(y2h_memcpy_d2h(h_probs, e->d_probs, (size_t)total * l.classes * sizeof(float), e->stream));
-    HIPCALL(y2h_stream_sync(e->stream));
+    HIPCALL_C(y2h_memcpy_d2h(boxes, e->d_boxes, (size_t)total * sizeof(box), e->stream));
+    HIPCALL_C(y2h_memcpy_d2h(h_probs, e->d_probs, (size_t)total * l.classes * sizeof(float), e->stream));
+    HIPCALL_C(y2h_stream_sync(e->stream));
     for (i = 0; i < total; ++i) memcpy(probs[i], h_probs + (size_t)i * l.classes, l.classes * sizeof(float));
+cleanup:
     free(h_probs);
     y2h_free(d_tmp);
 }
@@ -473,12 +477,13 @@ static int grow(void **p, size_t *cap, size_t need)
     return 0;
 }
 
-int y2_ingest_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox)
+/* the device half of y2_ingest_u8: `d_frames` already sits in HBM */
+int y2_ingest_u8_device(network net, const unsigned char *d_frames, int h, int w, int c, int step, int swap_rb, int letterbox)
 {
     y2_engine *e;
     size_t frame_bytes, nplanes, ntmp = 0;
     int planes, nw = net.w, nh = net.h;
-    if (!frames || h <= 0 || w <= 0 || c <= 0 || step < w * c) { y2_fail("y2_ingest_u8: bad frame geometry"); return -1; }
+    if (!d_frames || h <= 0 || w <= 0 || c <= 0 || step < w * c) { y2_fail("y2_ingest_u8: bad frame geometry"); return -1; }
     if (c < net.c) { y2_fail("y2_ingest_u8: frames have %d channels, the network reads %d", c, net.c); return -1; }
     if (y2_prepare(&net) != 0) return -1;
     e = y2_engine_of(&net);
@@ -486,10 +491,8 @@ int y2_ingest_u8(network net, const unsigned char *frames, int h, int w, int c, 
     planes = net.c;                       /* a 4th (alpha) plane is never read by the network (detector.c:567) */
     frame_bytes = (size_t)step * h;
     nplanes = (size_t)net.batch * planes * h * w;
-    if (grow((void **)&e->d_u8, &e->u8_cap, frame_bytes * net.batch)) { y2_fail("y2_ingest_u8: %s", y2h_last_error()); return -1; }
-    HIPCALL_I(y2h_memcpy_h2d(e->d_u8, frames, frame_bytes * net.batch, e->stream));
     if (w == net.w && h == net.h) {
-        HIPCALL_I(y2h_u8_to_planes(e->d_u8, net.batch, h, w, c, step, (long)frame_bytes, planes, swap_rb, e->d_in_nchw, e->stream));
+        HIPCALL_I(y2h_u8_to_planes(d_frames, net.batch, h, w, c, step, (long)frame_bytes, planes, swap_rb, e->d_in_nchw, e->stream));
         return 0;
     }
     if (letterbox) y2h_letterbox_dims(w, h, net.w, net.h, &nw, &nh);
@@ -498,11 +501,25 @@ int y2_ingest_u8(network net, const unsigned char *frames, int h, int w, int c, 
     if (grow((void **)&e->d_planes, &e->planes_cap, nplanes * 4) || grow((void **)&e->d_rtmp, &e->rtmp_cap, ntmp * 4)) {
         y2_fail("y2_ingest_u8: %s", y2h_last_error()); return -1;
     }
-    HIPCALL_I(y2h_u8_to_planes(e->d_u8, net.batch, h, w, c, step, (long)frame_bytes, planes, swap_rb, e->d_planes, e->stream));
+    HIPCALL_I(y2h_u8_to_planes(d_frames, net.batch, h, w, c, step, (long)frame_bytes, planes, swap_rb, e->d_planes, e->stream));
     /* planes are independent in resize/embed, so the whole batch goes through as batch*planes planes */
     if (letterbox) HIPCALL_I(y2h_letterbox_chw(e->d_planes, net.batch * planes, h, w, e->d_rtmp, e->d_in_nchw, net.h, net.w, e->stream));
     else HIPCALL_I(y2h_resize_chw(e->d_planes, net.batch * planes, h, w, e->d_rtmp, e->d_in_nchw, net.h, net.w, e->stream));
     return 0;
+}
+
+int y2_ingest_u8(network net, const unsigned char *frames, int h, int w, int c, int step, int swap_rb, int letterbox)
+{
+    y2_engine *e;
+    size_t frame_bytes;
+    if (!frames || h <= 0 || w <= 0 || c <= 0 || step < w * c) { y2_fail("y2_ingest_u8: bad frame geometry"); return -1; }
+    if (y2_prepare(&net) != 0) return -1;
+    e = y2_engine_of(&net);
+    HIPCALL_I(y2h_set_device(e->device));
+    frame_bytes = (size_t)step * h;
+    if (grow((void **)&e->d_u8, &e->u8_cap, frame_bytes * net.batch)) { y2_fail("y2_ingest_u8: %s", y2h_last_error()); return -1; }
+    HIPCALL_I(y2h_memcpy_h2d(e->d_u8, frames, frame_bytes * net.batch, e->stream));
+    return y2_ingest_u8_device(net, e->d_u8, h, w, c, step, swap_rb, letterbox);
 }
 
 /* A float CHW frame of any size (the `image` the reference's callers hold): its first net.c planes are uploaded

@@ -134,6 +134,7 @@ void y2_engine_destroy(network *net)
     if (!e) return;
     if (e->stream || e->arena || e->built) y2h_set_device(e->device);
     free_plan(net);
+    y2_feed_close(net);
     for (i = 0; i < net->n; ++i) {
         y2_ldev *d = ld_of(&net->layers[i]);
         if (!d) continue;
@@ -792,14 +793,42 @@ int y2_engine_build(network *net)
         }
         if (need) { HIPCALL(y2h_malloc((void **)&e->d_ws, need)); e->ws_bytes = need; }
     }
-    if (off != e->arena_bytes || !e->arena) {
-        if (e->arena) y2h_free(e->arena);
-        e->arena = NULL;
-        e->arena_bytes = off;
-        HIPCALL(y2h_malloc((void **)&e->arena, off));
-        if (!e->weights_external) e->weights_dirty = 1;
+    {   /* The packed arena is only valid for the layout it was filled for: a re-plan may move a layer between the
+         * matrix-core and the reference-layout form, or switch the weights to half, without changing the total size.
+         * Signature = FNV-1a over every per-layer offset and form flag. */
+        uint64_t sig = 1469598103934665603ull;
+#define SIG_MIX(v) do { uint64_t v_ = (uint64_t)(v); int b_; for (b_ = 0; b_ < 8; ++b_) { sig ^= (v_ >> (8 * b_)) & 0xff; sig *= 1099511628211ull; } } while (0)
+        for (i = 0; i < net->n; ++i) {
+            const layer *l = &net->layers[i];
+            const y2_ldev *d = ld_of(l);
+            if (l->type != CONVOLUTIONAL && l->type != CONNECTED && l->type != LOCAL && l->type != BATCHNORM) continue;
+            SIG_MIX(i); SIG_MIX(d->off_w_packed); SIG_MIX(d->has_w_ref ? d->off_w_ref + 1 : 0); SIG_MIX(d->off_bias);
+            SIG_MIX(d->uses_mfma); SIG_MIX((i > 0) && ld_of(&net->layers[i - 1])->out_half);
+            SIG_MIX(l->batch_normalize ? d->off_rinv + 1 : 0);
+        }
+        SIG_MIX(e->strict); SIG_MIX(e->half); SIG_MIX(off);
+#undef SIG_MIX
+        if (off != e->arena_bytes || !e->arena) {
+            if (e->arena) y2h_free(e->arena);
+            e->arena = NULL;
+            e->arena_bytes = off;
+            HIPCALL(y2h_malloc((void **)&e->arena, off));
+            e->arena_sig = 0;
+        }
+        if (sig != e->arena_sig) {
+            if (e->weights_external && e->arena_sig != 0) {
+                /* a replicated rank holds no host weights to re-pack from: silently keeping (or re-uploading zeros
+                 * over) an arena of another layout would compute garbage */
+                e->weights_external = 0;
+                y2_fail("the weight arena was filled from outside (y2_weights_resident) for another plan "
+                        "(strict / fp16 / fusion / size changed its layout): call y2_weights_arena() again and replicate the "
+                        "weights for the new plan");
+                return -1;
+            }
+            if (!e->weights_external) e->weights_dirty = 1;
+            e->arena_sig = sig;
+        }
     }
-    if (e->built_strict != e->strict || e->built_half != e->half) e->weights_dirty = e->weights_external ? e->weights_dirty : 1;
     /* timing events */
     if (e->n_ev != net->n + 1) {
         if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
@@ -1153,7 +1182,13 @@ int y2_weights_arena(network *net, void **dev_ptr, size_t *bytes)
     e = y2_engine_of(net);
     /* building must not try to upload host weights that were never loaded */
     keep = e->weights_dirty;
-    if (!e->built) { e->weights_external = 1; if (y2_engine_build(net) != 0) return -1; e->weights_external = 0; e->weights_dirty = keep; }
+    if (!e->built || e->built_strict != e->strict || e->built_half != e->half || e->built_fusion != e->fusion ||
+        e->built_batch != net->batch || e->built_w != net->w || e->built_h != net->h) {
+        /* (re-)requesting the arena: whatever layout it had before no longer binds */
+        e->weights_external = 1; e->arena_sig = 0;
+        if (y2_engine_build(net) != 0) { e->weights_external = 0; return -1; }
+        e->weights_external = 0; e->weights_dirty = keep;
+    }
     if (dev_ptr) *dev_ptr = e->arena;
     if (bytes) *bytes = e->arena_bytes;
     return 0;

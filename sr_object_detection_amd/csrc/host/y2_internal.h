@@ -69,6 +69,7 @@ typedef struct y2_engine {
     /* weight arena */
     unsigned char *arena;
     size_t arena_bytes;
+    uint64_t arena_sig;        /* hash of the per-layer offsets / forms the arena was laid out with (0: none yet) */
     /* io buffers */
     float *d_in_nchw, *d_in_nhwc;
     size_t in_floats;
@@ -96,6 +97,13 @@ typedef struct y2_engine {
     int *h_counts;
     int det_cap;               /* records per image */
     int det_batch, det_total, det_classes;
+    /* pinned, multi-buffered host feed (y2_feed.c) */
+    int feed_slots;
+    size_t feed_bytes;
+    void **feed_host, **feed_dev;
+    y2h_event *feed_up, *feed_done;    /* per slot: H2D finished / the forward that read the device copy was enqueued and ran */
+    int *feed_used;                    /* per slot: feed_done has been recorded at least once */
+    y2h_stream feed_stream;            /* copies run here, next to the engine stream's kernels */
     /* timing */
     y2h_event *ev;             /* n+1 events */
     int n_ev;
@@ -116,6 +124,7 @@ void y2_engine_host_output(network *net);
 int y2_engine_build(network *net);
 int y2_engine_forward(network *net, const float *d_input_nchw);
 int y2_engine_fetch_output(network *net);
+int y2_ingest_u8_device(network net, const unsigned char *d_frames, int h, int w, int c, int step, int swap_rb, int letterbox);
 
 /* cfg helpers shared with other files */
 char *y2_fgetl(FILE *fp);

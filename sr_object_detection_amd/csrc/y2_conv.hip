@@ -1035,6 +1035,7 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         }
         a.ntiles = (int)(tiles_m * a.tiles_n) * ksplit;
         long grid = 256L * variant_bpc(*v);          // persistent: at most what is co-resident
+        if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }   // tests: many tiles per workgroup on small shapes
         if (grid > a.ntiles) grid = a.ntiles;
         hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
         Y2H_LAUNCH_CHECK();

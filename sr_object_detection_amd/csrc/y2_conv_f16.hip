@@ -764,6 +764,7 @@ int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     }
     a.ntiles = (int)(tiles_m * a.tiles_n);
     long grid = 256L * bpc_h(*v);
+    if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }   // tests: many tiles per workgroup on small shapes
     if (grid > a.ntiles) grid = a.ntiles;
     hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
     Y2H_LAUNCH_CHECK();

@@ -106,6 +106,7 @@ extern "C" int y2h_event_create(y2h_event *e)
 extern "C" int y2h_event_destroy(y2h_event e) { if (e) Y2H_CHECK(hipEventDestroy((hipEvent_t)e)); return Y2H_OK; }
 extern "C" int y2h_event_record(y2h_event e, y2h_stream s) { Y2H_CHECK(hipEventRecord((hipEvent_t)e, S(s))); return Y2H_OK; }
 extern "C" int y2h_event_sync(y2h_event e) { Y2H_CHECK(hipEventSynchronize((hipEvent_t)e)); return Y2H_OK; }
+extern "C" int y2h_stream_wait_event(y2h_stream s, y2h_event e) { Y2H_CHECK(hipStreamWaitEvent(S(s), (hipEvent_t)e, 0)); return Y2H_OK; }
 extern "C" int y2h_event_elapsed_ms(y2h_event start, y2h_event stop, float *ms)
 {
     Y2H_CHECK(hipEventSynchronize((hipEvent_t)stop));

@@ -180,6 +180,23 @@ def lib():
     L.y2_layer_kernel.argtypes = [CNetwork, C.c_int]
     L.y2_weights_arena.argtypes = [C.POINTER(CNetwork), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.y2_weights_resident.argtypes = [C.POINTER(CNetwork)]
+    L.y2_feed_open.argtypes = [C.POINTER(CNetwork), C.c_int, C.c_size_t]
+    L.y2_feed_close.argtypes = [C.POINTER(CNetwork)]
+    L.y2_feed_host.restype = C.c_void_p
+    L.y2_feed_host.argtypes = [CNetwork, C.c_int]
+    L.y2_feed_device.restype = C.c_void_p
+    L.y2_feed_device.argtypes = [CNetwork, C.c_int]
+    L.y2_feed_slot_bytes.restype = C.c_size_t
+    L.y2_feed_slot_bytes.argtypes = [CNetwork]
+    L.y2_feed_submit.argtypes = [CNetwork, C.c_int, C.c_size_t]
+    L.y2_feed_wait_host.argtypes = [CNetwork, C.c_int]
+    L.y2_feed_forward.argtypes = [CNetwork, C.c_int]
+    L.y2_feed_forward_u8.argtypes = [CNetwork, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.y2_comm_library.restype = C.c_char_p
+    L.y2_comm_unique_id.argtypes = [C.c_void_p]
+    L.y2_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.y2_comm_destroy.argtypes = [C.c_void_p]
+    L.y2_broadcast_weights.argtypes = [C.POINTER(CNetwork), C.c_void_p, C.c_int]
     L.y2_network_predict_device.restype = C.POINTER(C.c_float)
     L.y2_network_predict_device.argtypes = [CNetwork, C.c_void_p]
     L.y2_forward_device.argtypes = [CNetwork, C.c_void_p]
@@ -403,6 +420,44 @@ class Network:
 
     def weights_resident(self) -> None:
         lib().y2_weights_resident(C.byref(self.net))
+
+    def broadcast_weights(self, comm: int, root: int = 0) -> None:
+        """one in-place RCCL broadcast of the packed arena (include/sr_yolo2.h y2_broadcast_weights)"""
+        if lib().y2_broadcast_weights(C.byref(self.net), C.c_void_p(comm), root) != 0:
+            raise Y2Error("y2_broadcast_weights: " + _check())
+
+    # --- pinned, multi-buffered host feed (include/sr_yolo2.h y2_feed_*) ---
+    def feed_open(self, slots: int = 2, slot_bytes: int = 0) -> None:
+        if lib().y2_feed_open(C.byref(self.net), slots, slot_bytes) != 0:
+            raise Y2Error("y2_feed_open: " + _check())
+
+    def feed_close(self) -> None:
+        lib().y2_feed_close(C.byref(self.net))
+
+    def feed_host(self, slot: int, dtype=np.float32) -> np.ndarray:
+        """numpy view of the slot's PINNED host buffer (the producer writes frames here)"""
+        p = lib().y2_feed_host(self.net, slot)
+        if not p:
+            raise Y2Error("y2_feed_host: " + _check())
+        n = lib().y2_feed_slot_bytes(self.net)
+        buf = (C.c_ubyte * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype)
+
+    def feed_submit(self, slot: int, nbytes: int = 0) -> None:
+        if lib().y2_feed_submit(self.net, slot, nbytes) != 0:
+            raise Y2Error("y2_feed_submit: " + _check())
+
+    def feed_wait_host(self, slot: int) -> None:
+        if lib().y2_feed_wait_host(self.net, slot) != 0:
+            raise Y2Error("y2_feed_wait_host: " + _check())
+
+    def feed_forward(self, slot: int) -> None:
+        if lib().y2_feed_forward(self.net, slot) != 0:
+            raise Y2Error("y2_feed_forward: " + _check())
+
+    def feed_forward_u8(self, slot: int, h: int, w: int, c: int, step: int = 0, swap_rb: bool = True, letterbox: bool = False) -> None:
+        if lib().y2_feed_forward_u8(self.net, slot, h, w, c, step or w * c, 1 if swap_rb else 0, 1 if letterbox else 0) != 0:
+            raise Y2Error("y2_feed_forward_u8: " + _check())
 
     def forward_device(self, d_input: int) -> None:
         if lib().y2_forward_device(self.net, C.c_void_p(d_input)) != 0:
@@ -670,6 +725,35 @@ def letterbox_image(im: np.ndarray, w: int, h: int, into: np.ndarray | None = No
     if failed:
         raise Y2Error("letterbox_image: " + _check())
     return arr
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL unique id (rank 0 creates it and hands it to the other ranks)"""
+    buf = C.create_string_buffer(128)
+    if lib().y2_comm_unique_id(buf) != 0:
+        raise Y2Error("y2_comm_unique_id: " + _check())
+    return buf.raw
+
+
+def comm_init_rank(nranks: int, uid: bytes, rank: int, device: int) -> int:
+    comm = C.c_void_p()
+    if len(uid) != 128:
+        raise Y2Error("comm_init_rank: the unique id must be 128 bytes")
+    if lib().y2_comm_init_rank(C.byref(comm), nranks, C.create_string_buffer(uid, 128), rank, device) != 0:
+        raise Y2Error("y2_comm_init_rank: " + _check())
+    return comm.value
+
+
+def comm_destroy(comm: int) -> None:
+    if lib().y2_comm_destroy(C.c_void_p(comm)) != 0:
+        raise Y2Error("y2_comm_destroy: " + _check())
+
+
+def comm_library() -> str:
+    p = lib().y2_comm_library()
+    if not p:
+        raise Y2Error("y2_comm_library: " + _check())
+    return p.decode()
 
 
 def device_count() -> int:

@@ -3,7 +3,7 @@
 The engine parses ordinary Darknet .cfg files (the grammar of
 src_yolo2/parser.c:702-735).  The reference's cfg/*.cfg files do not travel to
 the GPU box, so the benchmark/test networks are emitted here from compact
-specs; tests/test_cfg_equivalence.py checks, when /root/reference is present,
+specs; tests/test_capi_host.py checks, when /root/reference is present,
 that each emitted text parses to the same layer table as the reference's own
 cfg file (cfg/yolo.cfg, cfg/tiny-yolo-voc.cfg, cfg/yolo9000.cfg,
 cfg/darknet19_448.cfg).

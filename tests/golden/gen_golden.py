@@ -52,8 +52,19 @@ CASES = [
     ("mini_v1_local_40_b2", "mini-v1-local", 40, 2, 91, 0.2, 0.4, 1.0),
     ("mini_acts_32_b2", "mini-acts", 32, 2, 101, 0.05, 0.4, 4.0),
     ("mini_xnor_32_b2", "mini-xnor", 32, 2, 111, 0.3, 0.4, 4.0),
-    ("mini_cls_75_b2", "mini-cls", 75, 2, 121, 0.0, 0.0, 1.0),          # classifier shapes: 7x7/2, 5x5, padded / unpadded pools, strides          # xnor=1 convolutions + standalone [batchnorm]      # the nine activations the target cfgs do not use   # [crop] [batchnorm] [local] in front of the YOLOv1 head
+    ("mini_cls_75_b2", "mini-cls", 75, 2, 121, 0.0, 0.0, 1.0),
+    # the BASELINE.json configurations at their full input size (tests/test_gpu_configs.py fills the configs' batch --
+    # 8 / 32 / 8 per GPU / 128 -- with these images, so every batch item has a reference answer)
+    ("yolo_416_b4", "yolo", 416, 4, 131, 0.2, 0.4, 4.0),
+    ("yolo_608_b4", "yolo", 608, 4, 831, 0.2, 0.4, 4.0),
+    ("yolo9000_544_b2", "yolo9000", 544, 2, 151, 0.2, 0.4, 4.0),
+    ("darknet19_448_b8", "darknet19", 448, 8, 161, 0.0, 0.0, 1.0),          # classifier shapes: 7x7/2, 5x5, padded / unpadded pools, strides          # xnor=1 convolutions + standalone [batchnorm]      # the nine activations the target cfgs do not use   # [crop] [batchnorm] [local] in front of the YOLOv1 head
 ]
+
+
+# the region tensor of yolo9000 at 544x544 is 32 MB per image: the fixture keeps every OUT_STRIDE-th value (+ the sum,
+# the per-layer statistics and the complete decode / NMS results)
+OUT_STRIDE = {"yolo9000_544_b2": 61}
 
 
 def materialize(tmp: str, net: str, size: int, batch: int, seed: int, head_gain: float, use_map: bool = False):
@@ -148,6 +159,10 @@ def generate_case(name, net, size, batch, seed, thresh, nms, gain, use_map):
                 "out": out,
                 "input_checksum": np.float64(x.astype(np.float64).sum()),
             }
+            if name in OUT_STRIDE:
+                fix["out"] = out[::OUT_STRIDE[name]].copy()
+                fix["out_stride"] = OUT_STRIDE[name]
+                fix["out_sum"] = np.float64(out.astype(np.float64).sum())
             if use_map:                        # same forward tensor as the non-map case: keep the fixture small
                 fix["out"] = out[:0]
                 fix["out_sum"] = np.float64(out.astype(np.float64).sum())

@@ -1,0 +1,146 @@
+"""Every tile instantiation of the matrix-core convolutions against the CPU oracle, bit for bit.
+
+The host picks a tile per layer from the grid size (pick_variant, y2_conv.hip; pick_h, y2_conv_f16.hip), so small
+test networks only ever reach the small tiles.  Here each instantiated shape is FORCED (Y2_CONV_TILE) on a layer whose
+pixel count and filter count are not multiples of the tile (partial edge tiles in both GEMM dimensions, tiles that
+straddle two images), with the persistent grid capped (Y2_CONV_GRID) so that every workgroup walks several tiles and
+the cross-tile prefetch of the staging side runs, with 1x1 and 3x3 filters, both K-slice depths, with and without the
+fused 2x2 maxpool, and K-split for the tiles that use it.  Integer-valued data make every fp32 partial sum exact in
+any order, so the result must EQUAL the oracle's (convolutional_layer.c:435-474, gemm.c:74-88 restated in
+oracle/y2_oracle.c); the fp16 kernels must equal it rounded once to half.
+
+TESTED_F32 / TESTED_F16 are also what tests/test_gpu_configs.py holds the BASELINE workloads to: a kernel name the
+benchmark times must be in these sets."""
+import re
+
+import numpy as np
+import pytest
+
+from sr_object_detection_amd import darknet
+from tests.test_gpu_kernels import _small_int_conv_case
+
+pytestmark = pytest.mark.gpu
+
+# (BM, BN): every fp32 instantiation of conv_mfma_kernel for 1x1 / 3x3 filters (g_variants, y2_conv.hip)
+F32_TILES_BK32 = [(192, 256), (256, 128), (256, 64), (128, 128), (128, 64), (64, 64), (128, 32)]
+F32_TILES_BK16 = [(128, 128), (128, 64), (64, 64), (128, 32)]
+# fp16: (BM, BN, m16) -- g_variants_h, y2_conv_f16.hip
+F16_TILES = [(256, 256, True), (256, 256, False), (256, 128, False), (256, 64, False), (128, 128, False), (128, 64, False),
+             (64, 64, False)]
+
+TESTED_F32 = {"conv_mfma_f32_%dx%dx%d_k%d" % (bm, bn, bk, ks) for bk, tiles in ((32, F32_TILES_BK32), (16, F32_TILES_BK16))
+              for (bm, bn) in tiles for ks in (1, 3)}
+TESTED_F16 = {"conv_mfma_f16_%dx%dx%d_k%d" % (bm, bn, bk, ks) for (bm, bn, _) in F16_TILES for bk in (64, 32) for ks in (1, 3)}
+
+
+def _as_half(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def _run(oracle, workdir, monkeypatch, *, cin, filters, ksize, size, batch, tile, pool, half=False, no_m16=False,
+         grid=3, ksplit=1, bn=0, act="linear", seed=0):
+    spec = [("conv", cin, 3, 0, "linear"), ("conv", filters, ksize, bn, act)]
+    if pool:
+        spec.append(("max", 2, 2))
+    cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 20000 + seed)
+    monkeypatch.setenv("Y2_CONV_TILE", "%dx%d" % tile)
+    monkeypatch.setenv("Y2_CONV_GRID", str(grid))
+    monkeypatch.setenv("Y2_CONV_KSPLIT", str(ksplit))
+    if no_m16:
+        monkeypatch.setenv("Y2_NO_M16", "1")
+    else:
+        monkeypatch.delenv("Y2_NO_M16", raising=False)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    if half:
+        net.set_half(True)
+    out = net.network_predict(x)
+    name = net.layer_kernel(1)
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    l0 = np.abs(on.layer_output(0)).max()
+    net.free()
+    on.close()
+    return out, ref, name, l0
+
+
+_seed = [0]
+
+
+def _next_seed():
+    _seed[0] += 1
+    return _seed[0]
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("ksize", [1, 3])
+@pytest.mark.parametrize("bk,tile", [(32, t) for t in F32_TILES_BK32] + [(16, t) for t in F32_TILES_BK16],
+                         ids=lambda v: "%dx%d" % v if isinstance(v, tuple) else "bk%d" % v)
+def test_f32_tile_is_exact(oracle, workdir, monkeypatch, bk, tile, ksize, pool):
+    bm, bn = tile
+    cin = 64 if bk == 32 else 48
+    filters = bn + 40                       # two filter tiles, the second partial
+    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=cin, filters=filters, ksize=ksize, size=26, batch=2, tile=tile,
+                             pool=pool, seed=bm * 7 + bn * 3 + bk + ksize * 100 + pool * 1000)
+    assert name == "conv_mfma_f32_%dx%dx%d_k%d%s" % (bm, bn, bk, ksize, "+maxpool2" if pool else ""), name
+    assert name.split("+")[0] in TESTED_F32
+    assert np.abs(ref).max() < 2 ** 22
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("tile", F32_TILES_BK32, ids=lambda t: "%dx%d" % t)
+def test_f32_tile_split_k_is_exact(oracle, workdir, monkeypatch, tile):
+    """the K loop of a tile cut into three uneven ranges (27 slices of a 3x3x96 filter -> 9/9/9; 18 -> 6/6/6 at BK 32),
+    partial sums through the workspace, splitk_reduce_kernel"""
+    bm, bn = tile
+    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=96, filters=bn + 24, ksize=3, size=19, batch=3, tile=tile,
+                             pool=False, ksplit=4, seed=5000 + bm + bn)
+    assert name == "conv_mfma_f32_%dx%dx32_k3" % (bm, bn), name
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("tile", F32_TILES_BK32, ids=lambda t: "%dx%d" % t)
+def test_f32_tile_with_batchnorm_leaky_epilogue(oracle, workdir, monkeypatch, tile, pool):
+    """the epilogue copy compiled with batch-norm + leaky as constants (every conv of the BASELINE cfgs but the last):
+    same exact accumulator, epilogue arithmetic as blas.c:122 / convolutional_layer.c:407-419 / activations.h:41 -- the
+    double reciprocal instead of the double divide may differ by one fp32 ulp"""
+    bm, bn = tile
+    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=64, filters=bn + 40, ksize=3, size=26, batch=2, tile=tile,
+                             pool=pool, bn=1, act="leaky", seed=9000 + bm + bn + pool)
+    assert name.startswith("conv_mfma_f32_%dx%dx32_k3" % (bm, bn)), name
+    assert np.abs(out - ref).max() <= np.abs(ref).max() * 2.0 ** -23
+    assert (out != ref).mean() < 1e-3
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("ksize", [1, 3])
+@pytest.mark.parametrize("bk", [64, 32])
+@pytest.mark.parametrize("tile", F16_TILES, ids=lambda t: "%dx%d%s" % (t[0], t[1], "_m16" if t[2] else ""))
+def test_f16_tile_is_exact(oracle, workdir, monkeypatch, tile, bk, ksize, pool):
+    bm, bn, m16 = tile
+    cin = 64 if bk == 64 else 96
+    filters = bn + 40                       # a multiple of 8: the 16-byte store path (required by the 16x16x32 variant)
+    out, ref, name, l0 = _run(oracle, workdir, monkeypatch, cin=cin, filters=filters, ksize=ksize, size=26, batch=2,
+                              tile=(bm, bn), pool=pool, half=True, no_m16=not m16,
+                              seed=30000 + bm * 7 + bn * 3 + bk + ksize * 100 + pool * 1000 + m16)
+    assert name == "conv_mfma_f16_%dx%dx%d_k%d%s" % (bm, bn, bk, ksize, "+maxpool2" if pool else ""), name
+    assert name.split("+")[0] in TESTED_F16
+    assert l0 <= 2048 and np.abs(ref).max() < 60000          # layer 0 exact in half, no overflow
+    assert np.array_equal(out, _as_half(ref))
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("tile", [t for t in F16_TILES if not t[2]], ids=lambda t: "%dx%d" % (t[0], t[1]))
+def test_f16_tile_scalar_store_path_is_exact(oracle, workdir, monkeypatch, tile, pool):
+    """a filter count that is not a multiple of 8 takes the 2-byte store epilogue"""
+    bm, bn, _ = tile
+    out, ref, name, l0 = _run(oracle, workdir, monkeypatch, cin=64, filters=bn + 37, ksize=3, size=26, batch=2,
+                              tile=(bm, bn), pool=pool, half=True, seed=40000 + bm + bn + pool)
+    assert name.startswith("conv_mfma_f16_%dx%dx64_k3" % (bm, bn)), name
+    assert np.array_equal(out, _as_half(ref))
+
+
+def test_kernel_name_pattern():
+    for n in sorted(TESTED_F32 | TESTED_F16):
+        assert re.fullmatch(r"conv_mfma_f(32|16)_\d+x\d+x\d+_k[13]", n)
