@@ -808,6 +808,7 @@ int y2_engine_build(network *net)
         }
         SIG_MIX(e->strict); SIG_MIX(e->half); SIG_MIX(off);
 #undef SIG_MIX
+        const int had_layout = e->arena_sig != 0;
         if (off != e->arena_bytes || !e->arena) {
             if (e->arena) y2h_free(e->arena);
             e->arena = NULL;
@@ -816,7 +817,7 @@ int y2_engine_build(network *net)
             e->arena_sig = 0;
         }
         if (sig != e->arena_sig) {
-            if (e->weights_external && e->arena_sig != 0) {
+            if (e->weights_external && had_layout) {
                 /* a replicated rank holds no host weights to re-pack from: silently keeping (or re-uploading zeros
                  * over) an arena of another layout would compute garbage */
                 e->weights_external = 0;
