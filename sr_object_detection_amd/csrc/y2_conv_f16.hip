@@ -446,6 +446,334 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 }
 
 // ---------------------------------------------------------------------------
+// 256x256x64 tile, LDS-DMA staging, eight phases per two K-tiles (the dominant fp16 kernel).
+//
+// The register-staged kernel above spends its K loop at about twice its pure-MFMA time: per K-tile every thread
+// issues 8 buffer loads, holds them in 32 VGPRs, writes them to LDS with 8 ds_write_b128 and the whole workgroup meets
+// at one barrier, with both waves of a SIMD reaching their matrix work, their LDS bursts and that barrier together
+// (profiles/r01_notes.md).  This kernel is built around `buffer_load_dwordx4 ... lds` instead:
+//
+//   * staging is LDS-DMA: no staging VGPRs, no ds_write; a wave-instruction moves 8 rows x 128 B (one 64-channel
+//     chunk of one filter tap of 8 pixels, or of 8 filters).  The DMA destination is lane-linear (wave base + lane*16),
+//     so rows cannot be padded; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the
+//     16-byte chunk index with (row >> 1) & 7, applied to the per-lane SOURCE address of the DMA and to the read
+//     address (both sides or neither).  Padding taps and rows past the end are out-of-range buffer offsets: the DMA
+//     writes zeros (tools/probes/glds_oob.hip).
+//   * a K-tile (64 channels of one tap) is four half-tiles of 16 KB -- A-h0 (GEMM rows 0..127), B-h0 (filters 0..127),
+//     B-h1, A-h1 -- in one of two 64 KB buffers.  A wave (wm, wn) owns rows {64 wm .. +64} of EACH A half and filters
+//     {32 wn .. +32} of EACH B half, so its 128 x 64 output is four quadrants (A half, B half) and a K-tile is four
+//     phases of 16 v_mfma_f32_16x16x32_f16 each: (A0,B0) (A0,B1) (A1,B1) (A1,B0).  A phase reads only the fragments it
+//     introduces (A0+B0: 12 ds_read_b128, B1: 4, A1: 8, none) and issues the DMA of ONE half-tile, five half-tiles ahead
+//     of the half-tile first read in it, across K-tile and tile boundaries (persistent workgroups).
+//   * phase = { fragment reads, 2 DMA, s_waitcnt vmcnt(6) } s_barrier { lgkmcnt(0), 16 MFMA } s_barrier.  vmcnt(6)
+//     leaves three half-tiles in flight and retires the one first read in the NEXT phase; the waits never drain
+//     (raw s_barrier: __syncthreads() would add vmcnt(0)).  Waves 4..7 run one barrier behind waves 0..3, so on every
+//     SIMD one wave is in its matrix segment while its partner reads fragments and issues DMA.
+//     Hazards, counted in phases: a half-tile is read >= 1 phase after the wait + barrier that retire it (read-after-
+//     write), and a slot is re-filled >= 3 phases after its last fragment read (write-after-read; 2 are needed with the
+//     one-barrier skew between the wave groups).
+//   * the epilogue is the 16x16-tile one of the register-staged kernel (folded batch-norm, activation, optional 2x2
+//     maxpool over the four accumulator registers of a lane, 16-byte stores through a wave-private LDS transpose) with
+//     its own 20 KB of LDS, so it never touches a buffer a DMA may be writing.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int KS>
+__global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
+{
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int HALF_B = 128 * 128;           // bytes of a half-tile: 128 rows x 64 halves
+    constexpr int BUF_B = 4 * HALF_B;           // A-h0 | A-h1 | B-h0 | B-h1
+    constexpr int ES = 40;                      // epilogue scratch row stride in halves (32 filters + 16 B)
+    extern __shared__ __attribute__((aligned(16))) unsigned char p8_smem[];     // [2][BUF_B] + [8 waves][32][ES] halves
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
+    const int l16 = lane & 15, lq = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+
+    // ---- staging role: 16-byte chunk `sc` of rows sr + 64 q (q = 0..3) of the A tile and of the B tile ----
+    const int sc = t & 7, sr = t >> 3;
+    const unsigned scs = (unsigned)(sc ^ ((sr >> 1) & 7)) * 16u;      // swizzled source chunk (bytes); (row >> 1) & 7 == (sr >> 1) & 7
+    unsigned a_off[4], a_msk[4], b_off[4];
+    const int nk = KS * KS * (a.Cin / BK);
+    auto tile_at = [&](int i) -> int {
+        const long tl = (long)blockIdx.x + (long)i * gridDim.x;
+        return tl < a.ntiles ? (int)tl : a.ntiles;
+    };
+    auto setup_tile = [&](int tile) {
+        const bool live = tile < a.ntiles;
+        const int p0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+        const int Wu = a.pool ? a.W >> 1 : a.W, Hu = a.pool ? a.H >> 1 : a.H;
+        const int r0 = p0 + sr;
+        const int u0 = a.pool ? r0 >> 2 : r0, tc = r0 & 3;       // rows of one thread are 64 apart: same pooling-window corner
+        int cn = u0 / (Hu * Wu);
+        int cy = (u0 - cn * Hu * Wu) / Wu, cx = u0 - cn * Hu * Wu - cy * Wu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q * 64;
+            const int py = a.pool ? 2 * cy + (tc >> 1) : cy, px = a.pool ? 2 * cx + (tc & 1) : cx;
+            a_off[q] = (unsigned)((cn * a.H + py) * a.W + px) * (unsigned)a.ldx * 2u + scs;
+            unsigned m = 0;
+            if (live && r < a.npix) {
+                if (KS == 1) m = 1u;
+                else {
+                    const unsigned xm = (px > 0 ? 1u : 0u) | 2u | (px < a.W - 1 ? 4u : 0u);
+                    const unsigned ym = (py > 0 ? 1u : 0u) | 8u | (py < a.H - 1 ? 64u : 0u);
+                    m = xm * ym;
+                }
+            }
+            a_msk[q] = m;
+            cx += a.pool ? 16 : 64;
+            while (cx >= Wu) { cx -= Wu; if (++cy >= Hu) { cy = 0; ++cn; } }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned co = (unsigned)(n0 + sr + q * 64);
+            b_off[q] = (live && co < (unsigned)a.Cout) ? co * (unsigned)a.K * 2u + scs : a.wbytes;
+        }
+    };
+    // cursor of the staging side: K-tile (s_tap, s_c0) of tile s_lti, in LDS buffer s_buf
+    int s_tap = 0, s_c0 = 0, s_kt = 0, s_lti = 0, s_buf = 0;
+    setup_tile(tile_at(0));
+    // one half-tile = two DMA instructions per thread: J = 0 A-h0, 1 B-h0, 2 B-h1, 3 A-h1
+    auto stage = [&](auto JC) {
+        constexpr int J = decltype(JC)::value;
+        constexpr bool IS_A = (J == 0 || J == 3);
+        constexpr int Q0 = (J == 0 || J == 1) ? 0 : 2;
+        constexpr int SLOT = J == 0 ? 0 : J == 3 ? 1 : J == 1 ? 2 : 3;
+        unsigned char *dst = p8_smem + s_buf * BUF_B + SLOT * HALF_B + wv * (8 * 128);      // + lane * 16 by the DMA
+        if (IS_A) {
+            int delta = 0;
+            if (KS == 3) {
+                const int kh = s_tap / 3, kw = s_tap - kh * 3;
+                delta = ((kh - 1) * a.W + (kw - 1)) * a.ldx;
+            }
+            const unsigned add = (unsigned)((delta + s_c0) * 2);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool ok = (a_msk[Q0 + u] >> s_tap) & 1u;
+                const unsigned off = ok ? a_off[Q0 + u] + add : a.xbytes;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void *)(dst + u * (64 * 128)), 16, off, 0, 0, 0);
+            }
+        } else {
+            const unsigned kadd = (unsigned)((s_tap * a.Cin + s_c0) * 2);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned off = (b_off[Q0 + u] == a.wbytes) ? a.wbytes : b_off[Q0 + u] + kadd;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void *)(dst + u * (64 * 128)), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    auto advance = [&]() {        // the cursor moves to the next K-tile (of the next tile after the last one)
+        s_buf ^= 1;
+        if (++s_tap == KS * KS) { s_tap = 0; s_c0 += BK; }
+        if (++s_kt == nk) { s_kt = 0; s_tap = 0; s_c0 = 0; setup_tile(tile_at(++s_lti)); }
+    };
+
+    // ---- matrix side: fragment addresses.  Lane (l16, lq) of a 16x16x32 operand holds k = 32 kk + 8 lq .. +7 of row l16 ----
+    const unsigned swz = (unsigned)((l16 >> 1) & 7);
+    const unsigned fo0 = (unsigned)l16 * 128u + (((unsigned)lq) ^ swz) * 16u;             // kk = 0
+    const unsigned fo1 = (unsigned)l16 * 128u + (((unsigned)(4 + lq)) ^ swz) * 16u;       // kk = 1
+    const unsigned a_base = (unsigned)wm * (64u * 128u), b_base = 2u * HALF_B + (unsigned)wn * (32u * 128u);
+
+    f32x4 acc[2][2][4][2];            // [A half][B half][row tile][filter tile]
+    f16x8 af[4][2], bf0[2][2], bf1[2][2];
+
+    // prologue: half-tiles 0..4 (K-tile 0 whole, A-h0 of K-tile 1), the first two retired before the first phase
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    advance();
+    stage(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 1) __builtin_amdgcn_s_barrier();        // waves 4..7 run one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    int cbuf = 0;
+    for (int cti = 0;; ++cti) {
+        const int ct = tile_at(cti);
+        if (ct >= a.ntiles) break;
+        const int p0 = (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[x][y][i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char *buf = p8_smem + cbuf * BUF_B;
+            // ---------------- phase 0: (A0, B0) ----------------
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf0[j][0] = *(const f16x8 *)(buf + b_base + j * 2048 + fo0);
+                bf0[j][1] = *(const f16x8 *)(buf + b_base + j * 2048 + fo1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *(const f16x8 *)(buf + a_base + i * 2048 + fo0);
+                af[i][1] = *(const f16x8 *)(buf + a_base + i * 2048 + fo1);
+            }
+            stage(std::integral_constant<int, 1>{});
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[0][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf0[j][kk], acc[0][0][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- phase 1: (A0, B1) ----------------
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf1[j][0] = *(const f16x8 *)(buf + b_base + HALF_B + j * 2048 + fo0);
+                bf1[j][1] = *(const f16x8 *)(buf + b_base + HALF_B + j * 2048 + fo1);
+            }
+            stage(std::integral_constant<int, 2>{});
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[0][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf1[j][kk], acc[0][1][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- phase 2: (A1, B1) ----------------
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *(const f16x8 *)(buf + HALF_B + a_base + i * 2048 + fo0);
+                af[i][1] = *(const f16x8 *)(buf + HALF_B + a_base + i * 2048 + fo1);
+            }
+            stage(std::integral_constant<int, 3>{});
+            advance();
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[1][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf1[j][kk], acc[1][1][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- phase 3: (A1, B0) ----------------
+            stage(std::integral_constant<int, 0>{});
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[1][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf0[j][kk], acc[1][0][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            cbuf ^= 1;
+        }
+
+        // ---- epilogue (no barrier inside: the wave groups keep their one-barrier skew across tiles) ----
+        auto epilogue_pass = [&](auto LEAKYC) {
+            const int ACT_ = decltype(LEAKYC)::value ? (int)Y2H_ACT_LEAKY : a.act;
+            _Float16 *yh = (_Float16 *)a.y;
+            _Float16 *es = (_Float16 *)(p8_smem + 2 * BUF_B) + wv * 32 * ES;
+            const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int cb = n0 + y * 128 + wn * 32;             // 32 filters: two 16-wide MFMA tiles
+                const int c0f = cb + l16, c1f = cb + 16 + l16;
+                const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
+                const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    if (a.pool) {
+#pragma unroll
+                        for (int ip = 0; ip < 2; ++ip) {            // two 16-row tiles = 8 pooled rows
+                            const int pb = p0 + x * 128 + wm * 64 + ip * 32;
+#pragma unroll
+                            for (int ti = 0; ti < 2; ++ti) {
+                                const f32x4 q0 = acc[x][y][2 * ip + ti][0], q1 = acc[x][y][2 * ip + ti][1];
+                                float m0 = epilogue_fast(q0[0], al0, be0, ACT_), m1 = epilogue_fast(q1[0], al1, be1, ACT_);
+#pragma unroll
+                                for (int u = 1; u < 4; ++u) {
+                                    m0 = __builtin_fmaxf(m0, epilogue_fast(q0[u], al0, be0, ACT_));
+                                    m1 = __builtin_fmaxf(m1, epilogue_fast(q1[u], al1, be1, ACT_));
+                                }
+                                es[(ti * 4 + lq) * ES + l16] = (_Float16)m0;
+                                es[(ti * 4 + lq) * ES + 16 + l16] = (_Float16)m1;
+                            }
+                            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+                            const int prow = (pb >> 2) + rrow;
+                            if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int pb = p0 + x * 128 + wm * 64 + i * 16;
+                            const f32x4 q0 = acc[x][y][i][0], q1 = acc[x][y][i][1];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                es[(lq * 4 + r) * ES + l16] = (_Float16)epilogue_fast(q0[r], al0, be0, ACT_);
+                                es[(lq * 4 + r) * ES + 16 + l16] = (_Float16)epilogue_fast(q1[r], al1, be1, ACT_);
+                            }
+                            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+                            const int p = pb + rrow;
+                            if (p < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
+                        }
+                    }
+                }
+            }
+        };
+        if (a.act == Y2H_ACT_LEAKY) epilogue_pass(std::true_type{});
+        else epilogue_pass(std::false_type{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 0) __builtin_amdgcn_s_barrier();        // pairs with the extra barrier waves 4..7 took at the start
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead DMAs of the (masked) tiles past the end
+}
+
+// ---------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------
 struct VariantH {
@@ -456,6 +784,7 @@ struct VariantH {
     int threads;
     int minb;
     bool m16;          // 16x16x32 MFMA variant: needs the 16-byte output stores (vec_store)
+    bool p8;           // the LDS-DMA / eight-phase kernel (conv_p8_f16_kernel)
     bool attr_set[16];
 };
 
@@ -463,9 +792,15 @@ struct VariantH {
 // 512-entry register file of their SIMD (one wave per SIMD), everything else 256 registers per lane
 #define VARH(BM, BN, BK, KS, WM, WN, MINB, DB, M16)                                                  \
     { "conv_mfma_f16_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_f16_kernel<BM, BN, BK, KS, WM, WN, MINB, DB, M16>, \
-      (size_t)2 * (BM + BN) * (BK + 8) * sizeof(_Float16), WM * WN * 64, MINB, M16, {false} }
+      (size_t)2 * (BM + BN) * (BK + 8) * sizeof(_Float16), WM * WN * 64, MINB, M16, false, {false} }
+// same tile and name (tests and profiles address kernels by tile), different structure: see conv_p8_f16_kernel
+#define VARP8(KS)                                                                                    \
+    { "conv_mfma_f16_256x256x64_k" #KS, 256, 256, 64, KS, conv_p8_f16_kernel<KS>,                      \
+      (size_t)2 * 4 * 128 * 128 + (size_t)8 * 32 * 40 * sizeof(_Float16), 512, 1, true, true, {false} }
 
 static VariantH g_variants_h[] = {
+    // LDS-DMA staging, 8 phases per two K-tiles (first in the table: wins the tie against the register-staged 256x256)
+    VARP8(3), VARP8(1),
     // 256x256: eight waves of 128x64 (eight accumulator tiles each), two waves per SIMD, ONE workgroup per CU
     VARH(256, 256, 64, 3, 2, 4, 1, false, true), VARH(256, 256, 64, 1, 2, 4, 1, false, true),
     VARH(256, 256, 32, 3, 2, 4, 1, false, true), VARH(256, 256, 32, 1, 2, 4, 1, false, true),
@@ -713,12 +1048,14 @@ static VariantH *pick_h(const y2h_conv *d)
     if (const char *f = getenv("Y2_CONV_TILE")) sscanf(f, "%dx%d", &force_bm, &force_bn);
     const bool vec_ok = d->y_f16 && d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0;
     const bool no_m16 = getenv("Y2_NO_M16") != nullptr;      // A/B switch: keep to the 32x32x16 variants
+    const bool no_p8 = getenv("Y2_F16_NO_P8") != nullptr;    // A/B switch: the register-staged 256x256 kernel
     VariantH *best = nullptr;
     double best_cost = 0;
     for (VariantH &v : g_variants_h) {
         if (v.bk != bk || v.ks != d->size) continue;
         if (force_bm && (v.bm != force_bm || v.bn != force_bn)) continue;
         if (v.m16 && (!vec_ok || no_m16)) continue;
+        if (v.p8 && no_p8) continue;
         const long tiles = ((npix + v.bm - 1) / v.bm) * ((d->n + v.bn - 1) / v.bn);
         const int bpc = bpc_h(v);
         long per_cu;
