@@ -477,10 +477,21 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 //     its own 20 KB of LDS, so it never touches a buffer a DMA may be writing.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void;
+// Diagnostic build (-DP8_STAMPS, tools/build_variant.sh): every wave accumulates s_memtime deltas per phase segment and
+// writes them to a.ws at the end; y2_f16_conv_launch prints the averages.  Stamps cost ~10 % and serialise the fragment
+// reads in front of the first barrier; never compiled into the product.
+#ifdef P8_STAMPS
+#define P8_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define P8_STAMP(k) do { } while (0)
+#endif
 
 template <int KS>
 __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
 {
+#ifdef P8_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+#endif
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int HALF_B = 128 * 128;           // bytes of a half-tile: 128 rows x 64 halves
     constexpr int BUF_B = 4 * HALF_B;           // A-h0 | A-h1 | B-h0 | B-h1
@@ -500,8 +511,16 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
     const unsigned scs = (unsigned)(sc ^ ((sr >> 1) & 7)) * 16u;      // swizzled source chunk (bytes); (row >> 1) & 7 == (sr >> 1) & 7
     unsigned a_off[4], a_msk[4], b_off[4];
     const int nk = KS * KS * (a.Cin / BK);
+    // Optional XCD-aware placement (env Y2_P8_REMAP): workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share
+    // one L2); remapped, each XCD owns a contiguous run of tile numbers in every round.  Measured neutral to slightly
+    // negative on darknet19_448 b128 (the kernel is bound by the CU's own L2 -> LDS path, not by L2 misses), so it is off.
+    int wgid = blockIdx.x;
+    if (a.dbg & 64) {
+        const int nwg = gridDim.x, xcd = wgid & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wgid >> 3);
+    }
     auto tile_at = [&](int i) -> int {
-        const long tl = (long)blockIdx.x + (long)i * gridDim.x;
+        const long tl = (long)wgid + (long)i * gridDim.x;
         return tl < a.ntiles ? (int)tl : a.ntiles;
     };
     auto setup_tile = [&](int tile) {
@@ -539,13 +558,13 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
     // cursor of the staging side: K-tile (s_tap, s_c0) of tile s_lti, in LDS buffer s_buf
     int s_tap = 0, s_c0 = 0, s_kt = 0, s_lti = 0, s_buf = 0;
     setup_tile(tile_at(0));
-    // one half-tile = two DMA instructions per thread: J = 0 A-h0, 1 B-h0, 2 B-h1, 3 A-h1
-    auto stage = [&](auto JC) {
-        constexpr int J = decltype(JC)::value;
+    // one half-tile = two DMA instructions per thread (U = 0, 1): J = 0 A-h0, 1 B-h0, 2 B-h1, 3 A-h1
+    auto stage_one = [&](auto JC, auto UC) {
+        constexpr int J = decltype(JC)::value, U = decltype(UC)::value;
         constexpr bool IS_A = (J == 0 || J == 3);
-        constexpr int Q0 = (J == 0 || J == 1) ? 0 : 2;
+        constexpr int Q = ((J == 0 || J == 1) ? 0 : 2) + U;
         constexpr int SLOT = J == 0 ? 0 : J == 3 ? 1 : J == 1 ? 2 : 3;
-        unsigned char *dst = p8_smem + s_buf * BUF_B + SLOT * HALF_B + wv * (8 * 128);      // + lane * 16 by the DMA
+        unsigned char *dst = p8_smem + s_buf * BUF_B + SLOT * HALF_B + wv * (8 * 128) + U * (64 * 128);      // + lane * 16 by the DMA
         if (IS_A) {
             int delta = 0;
             if (KS == 3) {
@@ -553,20 +572,18 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
                 delta = ((kh - 1) * a.W + (kw - 1)) * a.ldx;
             }
             const unsigned add = (unsigned)((delta + s_c0) * 2);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bool ok = (a_msk[Q0 + u] >> s_tap) & 1u;
-                const unsigned off = ok ? a_off[Q0 + u] + add : a.xbytes;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void *)(dst + u * (64 * 128)), 16, off, 0, 0, 0);
-            }
+            const bool ok = (a_msk[Q] >> s_tap) & 1u;
+            const unsigned off = ok ? a_off[Q] + add : a.xbytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void *)dst, 16, off, 0, 0, 0);
         } else {
             const unsigned kadd = (unsigned)((s_tap * a.Cin + s_c0) * 2);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const unsigned off = (b_off[Q0 + u] == a.wbytes) ? a.wbytes : b_off[Q0 + u] + kadd;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void *)(dst + u * (64 * 128)), 16, off, 0, 0, 0);
-            }
+            const unsigned off = (b_off[Q] == a.wbytes) ? a.wbytes : b_off[Q] + kadd;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void *)dst, 16, off, 0, 0, 0);
         }
+    };
+    auto stage = [&](auto JC) {
+        stage_one(JC, std::integral_constant<int, 0>{});
+        stage_one(JC, std::integral_constant<int, 1>{});
     };
     auto advance = [&]() {        // the cursor moves to the next K-tile (of the next tile after the last one)
         s_buf ^= 1;
@@ -583,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
     f32x4 acc[2][2][4][2];            // [A half][B half][row tile][filter tile]
     f16x8 af[4][2], bf0[2][2], bf1[2][2];
 
-    // prologue: half-tiles 0..4 (K-tile 0 whole, A-h0 of K-tile 1), the first two retired before the first phase
+    // prologue: K-tile 0 whole and the first half-tiles of K-tile 1; the first two retired before the first phase
     stage(std::integral_constant<int, 0>{});
     stage(std::integral_constant<int, 1>{});
     stage(std::integral_constant<int, 2>{});
@@ -596,6 +613,69 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
     if (wm == 1) __builtin_amdgcn_s_barrier();        // waves 4..7 run one barrier behind
     __builtin_amdgcn_sched_barrier(0);
 
+    // One phase: fragment reads of the operands it introduces (RA: A half X, RB: B half Y), the two DMA instructions of
+    // half-tile J, the wait that retires the half-tile first read in the NEXT phase, barrier, 16 MFMAs on quadrant (X, Y),
+    // barrier.  In-kernel stamps (-DP8_STAMPS) put a phase at ~1150 cycles: fragment reads 100, the two DMAs 350, the wait
+    // for DMA data 10, barriers 85 + 260, MFMA issue 320 -- the kernel is bound by the ISSUE cost of the LDS-DMA
+    // instructions (1 KiB each, ~175 cycles), not by their latency.  Moving the DMAs between or behind the MFMAs, splitting
+    // them over both segments, a deeper prefetch, XCD-contiguous placement and dropping s_setprio all measured neutral to
+    // 20 % slower (profiles/r02_notes.md).
+    auto phase = [&](auto XC, auto YC, auto RAC, auto RBC, auto JC, auto ADVC, const unsigned char *buf) {
+        constexpr int X = decltype(XC)::value, Y = decltype(YC)::value;
+        constexpr bool RA = decltype(RAC)::value, RB = decltype(RBC)::value, ADV = decltype(ADVC)::value;
+        f16x8 (&bf)[2][2] = *(Y ? &bf1 : &bf0);
+        P8_STAMP(5);                                   // second-barrier wait of the previous phase
+        if (RB) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf[j][0] = *(const f16x8 *)(buf + b_base + Y * HALF_B + j * 2048 + fo0);
+                bf[j][1] = *(const f16x8 *)(buf + b_base + Y * HALF_B + j * 2048 + fo1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (RA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *(const f16x8 *)(buf + X * HALF_B + a_base + i * 2048 + fo0);
+                af[i][1] = *(const f16x8 *)(buf + X * HALF_B + a_base + i * 2048 + fo1);
+            }
+        }
+        P8_STAMP(0);                                   // fragment reads issued (and, with the stamp, returned)
+        stage(JC);
+        if (ADV) advance();
+        P8_STAMP(1);                                   // DMA issue
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        P8_STAMP(2);                                   // wait for the half-tile staged three phases ago
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (RA || RB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P8_STAMP(3);                                   // first-barrier wait
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[X][Y][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[X][Y][i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        P8_STAMP(4);                                   // matrix segment (issue of 16 MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    typedef std::true_type T_;
+    typedef std::false_type F_;
+
+#ifdef P8_STAMPS
+    st_prev = __builtin_amdgcn_s_memtime();
+#endif
     int cbuf = 0;
     for (int cti = 0;; ++cti) {
         const int ct = tile_at(cti);
@@ -613,103 +693,11 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
                         for (int r = 0; r < 4; ++r) acc[x][y][i][j][r] = 0.f;
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned char *buf = p8_smem + cbuf * BUF_B;
-            // ---------------- phase 0: (A0, B0) ----------------
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf0[j][0] = *(const f16x8 *)(buf + b_base + j * 2048 + fo0);
-                bf0[j][1] = *(const f16x8 *)(buf + b_base + j * 2048 + fo1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i][0] = *(const f16x8 *)(buf + a_base + i * 2048 + fo0);
-                af[i][1] = *(const f16x8 *)(buf + a_base + i * 2048 + fo1);
-            }
-            stage(std::integral_constant<int, 1>{});
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[0][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf0[j][kk], acc[0][0][i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- phase 1: (A0, B1) ----------------
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf1[j][0] = *(const f16x8 *)(buf + b_base + HALF_B + j * 2048 + fo0);
-                bf1[j][1] = *(const f16x8 *)(buf + b_base + HALF_B + j * 2048 + fo1);
-            }
-            stage(std::integral_constant<int, 2>{});
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[0][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf1[j][kk], acc[0][1][i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- phase 2: (A1, B1) ----------------
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i][0] = *(const f16x8 *)(buf + HALF_B + a_base + i * 2048 + fo0);
-                af[i][1] = *(const f16x8 *)(buf + HALF_B + a_base + i * 2048 + fo1);
-            }
-            stage(std::integral_constant<int, 3>{});
-            advance();
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[1][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf1[j][kk], acc[1][1][i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- phase 3: (A1, B0) ----------------
-            stage(std::integral_constant<int, 0>{});
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[1][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf0[j][kk], acc[1][0][i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+            // quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0); half-tile staged: the one first read D half-tiles later
+            phase(I0{}, I0{}, T_{}, T_{}, I1{}, F_{}, buf);
+            phase(I0{}, I1{}, F_{}, T_{}, I2{}, F_{}, buf);
+            phase(I1{}, I1{}, T_{}, F_{}, I3{}, T_{}, buf);
+            phase(I1{}, I0{}, F_{}, F_{}, I0{}, F_{}, buf);
             cbuf ^= 1;
         }
 
@@ -767,7 +755,12 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
         };
         if (a.act == Y2H_ACT_LEAKY) epilogue_pass(std::true_type{});
         else epilogue_pass(std::false_type{});
+        P8_STAMP(6);                                       // epilogue
     }
+#ifdef P8_STAMPS
+    if (lane == 0 && a.ws)
+        for (int k = 0; k < 8; ++k) ((unsigned long long *)a.ws)[((size_t)blockIdx.x * 8 + wv) * 8 + k] = st_acc[k];
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (wm == 0) __builtin_amdgcn_s_barrier();        // pairs with the extra barrier waves 4..7 took at the start
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead DMAs of the (masked) tiles past the end
@@ -1100,11 +1093,43 @@ int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
         if (dev >= 0 && dev < 16) v->attr_set[dev] = true;
     }
     a.ntiles = (int)(tiles_m * a.tiles_n);
+    if (v->p8 && getenv("Y2_P8_REMAP")) a.dbg |= 64;            // A/B: XCD-contiguous placement of workgroups
     long grid = 256L * bpc_h(*v);
     if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }   // tests: many tiles per workgroup on small shapes
     if (grid > a.ntiles) grid = a.ntiles;
+#ifdef P8_STAMPS
+    static unsigned long long *d_st = nullptr;
+    if (v->p8) {
+        if (!d_st) Y2H_CHECK(hipMalloc((void **)&d_st, 256 * 8 * 8 * sizeof(unsigned long long)));
+        Y2H_CHECK(hipMemsetAsync(d_st, 0, 256 * 8 * 8 * sizeof(unsigned long long), S(s)));
+        a.ws = (float *)d_st;
+    }
+#endif
     hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
     Y2H_LAUNCH_CHECK();
+#ifdef P8_STAMPS
+    if (v->p8 && getenv("Y2_P8_STAMPS")) {
+        static unsigned long long h[256 * 8 * 8];
+        Y2H_CHECK(hipStreamSynchronize(S(s)));
+        Y2H_CHECK(hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost));
+        const char *names[8] = {"frag reads", "dma issue", "vmcnt wait", "barrier1", "mfma issue", "barrier2", "epilogue", "dma2"};
+        const int nk = d->size * d->size * (d->c / 64);
+        for (int g = 0; g < 2; ++g) {
+            double tot[8] = {0}, phases = 0;
+            for (long b = 0; b < grid; ++b) {
+                const long tiles_b = (a.ntiles - b + grid - 1) / grid;
+                for (int w = 4 * g; w < 4 * g + 4; ++w) {
+                    phases += 4.0 * nk * tiles_b;
+                    for (int k = 0; k < 8; ++k) tot[k] += (double)h[(b * 8 + w) * 8 + k];
+                }
+            }
+            fprintf(stderr, "p8 stamps %dx%d c%d n%d waves %d-%d (shader cycles per phase):", d->h, d->w, d->c, d->n, 4 * g, 4 * g + 3);
+            double sum = 0;
+            for (int k = 0; k < 8; ++k) { fprintf(stderr, " %s %.0f", names[k], tot[k] / phases); sum += tot[k]; }
+            fprintf(stderr, " | total %.0f\n", sum / phases);
+        }
+    }
+#endif
     return Y2H_OK;
 }
 

@@ -23,6 +23,7 @@ def main():
     synth.write_weights(wts, zoo.resolve(name, size), 31)
     net = darknet.Network.parse_network_cfg(cfg)
     net.load_weights(wts)
+    net.set_half(bool(wl.get("half")))
     x = synth.image_batch(batch, 3, size, size)
     net.network_predict(x)
     net.set_timing(True)
