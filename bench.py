@@ -76,6 +76,8 @@ def parse_args():
                          "host_input, never as value); only: time just that; off: skip it")
     ap.add_argument("--bcast", default=os.environ.get("Y2_BENCH_BCAST", "torch"), choices=["torch", "c-abi"],
                     help="transport of the one weight broadcast at N>1")
+    ap.add_argument("--autotune", type=int, default=0,
+                    help="1: the plan measures the conv tile shapes once instead of modelling them (y2_set_autotune)")
     ap.add_argument("--dump-dets", default=None, help="write each rank's last-batch detections to PATH.rank<r>.npz")
     return ap.parse_args()
 
@@ -350,6 +352,7 @@ def main():
     L = darknet.lib()
     net = darknet.Network.parse_network_cfg(cfg, gpu=device_index)
     net.set_half(half)
+    net.set_autotune(bool(args.autotune))
     wts = os.path.join(tmp, "net.weights")
     if rank == 0:
         synth.write_weights(wts, layers, args.seed)
@@ -593,6 +596,7 @@ def main():
                            name + ".cfg", size, size, batch, what,
                            "inputs in pinned host memory (PCIe-inclusive)" if args.host_input == "only" else "inputs resident in HBM"),
                        "global_batch": batch * world, "parallelism": "frame-sharded x%d (one weight broadcast)" % world,
+                       "tile_choice": "measured at plan time (y2_set_autotune)" if args.autotune else "host cost model",
                        "weight_broadcast": bcast_how, "weight_broadcast_ms": bcast_ms,
                        "gflop_per_image": round(zoo.conv_flops(layers) / 1e9, 3),
                        "conv_ms_per_step": round(conv_ms, 3),

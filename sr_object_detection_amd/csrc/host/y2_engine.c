@@ -44,6 +44,7 @@ int y2_engine_create(network *net)
     e->fusion = getenv("Y2_NO_FUSE") ? 0 : 1;
     { const char *g = getenv("Y2_GRAPH"); e->graph_on = (g && atoi(g) != 0) ? 1 : 0; }
     { const char *hf = getenv("Y2_FP16"); e->half = (hf && atoi(hf) != 0) ? 1 : 0; }
+    { const char *at = getenv("Y2_AUTOTUNE"); e->autotune = (at && atoi(at) != 0) ? 1 : 0; }
     e->n_layers = net->n;
     e->out_layer = y2_out_layer(net);
     for (i = 0; i < net->n; ++i) {
@@ -99,6 +100,7 @@ static void free_plan(network *net)
         d->placed_in = -1; d->alias_of = -1; d->copy_mask = 0;
         d->fused_pool = 0; d->fused_into = -1;
         d->out_half = 0;
+        d->tile_bm = d->tile_bn = d->ksplit = 0;
     }
     if (e->graph) { y2h_graph_destroy(e->graph); e->graph = NULL; e->graph_src = NULL; }
     y2h_free(e->d_in_nchw); e->d_in_nchw = NULL;
@@ -211,6 +213,7 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     c->y = d->out;
     c->y_f16 = d->out_half;
     c->x_f16 = (i > 0) ? ld_of(&net->layers[i - 1])->out_half : (e->in_halo == 2);
+    c->tile_bm = d->tile_bm; c->tile_bn = d->tile_bn; c->ksplit = d->ksplit;
     if (e->arena) {
         c->w_packed = (const float *)(e->arena + d->off_w_packed);
         c->w_ref = d->has_w_ref ? (const float *)(e->arena + d->off_w_ref) : NULL;
@@ -407,6 +410,121 @@ static int upload_weights(network *net)
     }
     free(host);
     e->weights_dirty = 0;
+    return 0;
+}
+
+/* split-K scratch: the largest request of any conv layer under the current tile choices */
+static int size_workspace(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    size_t need = 0;
+    int i;
+    for (i = 0; i < net->n; ++i) {
+        y2h_conv c;
+        const float *x; int ldx;
+        size_t b;
+        if ((net->layers[i].type != CONVOLUTIONAL && net->layers[i].type != CONNECTED) || e->strict) continue;
+        input_view(net, i, &x, &ldx);
+        conv_desc(net, i, &c, x, ldx);
+        c.w_packed = (const float *)(uintptr_t)256;
+        b = y2h_conv_workspace_bytes(&c);
+        if (b > need) need = b;
+    }
+    if (need > e->ws_bytes) {
+        y2h_free(e->d_ws); e->d_ws = NULL; e->ws_bytes = 0;
+        HIPCALL(y2h_malloc((void **)&e->d_ws, need));
+        e->ws_bytes = need;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* tile autotuning (y2_set_autotune)                                   */
+/* ------------------------------------------------------------------ */
+/* Measured choices are remembered per layer shape for the life of the process, so that re-plans (set_batch_network,
+ * resize_network back and forth, several networks of one family) do not measure again. */
+typedef struct { int batch, h, w, c, n, size, stride, pool, bm, bn, ks; } tune_entry;
+static tune_entry g_tuned[256];
+static int g_ntuned = 0;
+
+static int enqueue_forward(network *net, const float *d_input_nchw);
+
+/* Candidates are timed INSIDE whole forward passes (per-layer HIP events, as y2_layer_times_ms reads them): timed in
+ * isolation, back to back, a layer finds its own weights in the Infinity Cache and small tiles look better than they are
+ * in the real sequence, where the 204 MB of yolo.cfg weights stream from HBM once per forward. */
+static int autotune_layers(network *net)
+{
+    y2_engine *e = y2_engine_of(net);
+    const int keep_timing = e->timing;
+    int i, k, a;
+    size_t need = 0;
+    for (i = 0; i < net->n; ++i) {          /* scratch for the largest K-split any candidate may ask for */
+        const layer *l = &net->layers[i];
+        y2_ldev *d = ld_of(l);
+        y2h_conv c;
+        const float *x; int ldx, n, bm[64], bn[64], ks[64];
+        if (l->type != CONVOLUTIONAL || !d->uses_mfma || l->xnor) continue;
+        input_view(net, i, &x, &ldx);
+        conv_desc(net, i, &c, x, ldx);
+        n = y2h_conv_candidates(&c, bm, bn, ks, 64);
+        for (a = 0; a < n; ++a) {
+            size_t b = (size_t)ks[a] * l->batch * l->out_h * l->out_w * l->out_c * sizeof(float);
+            if (ks[a] > 1 && b > need) need = b;
+        }
+    }
+    if (need > e->ws_bytes) {
+        y2h_free(e->d_ws); e->d_ws = NULL; e->ws_bytes = 0;
+        HIPCALL(y2h_malloc((void **)&e->d_ws, need));
+        e->ws_bytes = need;
+    }
+    e->timing = 1;
+    HIPCALL(y2h_memset(e->d_in_nchw, 0, e->in_floats * sizeof(float), e->stream));
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        y2_ldev *d = ld_of(l);
+        y2h_conv c;
+        const float *x; int ldx, n, hit = 0, bm[64], bn[64], ks[64], best = 0;
+        float best_ms = 0.f;
+        if (l->type != CONVOLUTIONAL || !d->uses_mfma || l->xnor) continue;
+        input_view(net, i, &x, &ldx);
+        conv_desc(net, i, &c, x, ldx);
+        for (k = 0; k < g_ntuned && !hit; ++k) {
+            const tune_entry *t = &g_tuned[k];
+            if (t->batch == c.batch && t->h == c.h && t->w == c.w && t->c == c.c && t->n == c.n && t->size == c.size &&
+                t->stride == c.stride && t->pool == c.fuse_maxpool2) { d->tile_bm = t->bm; d->tile_bn = t->bn; d->ksplit = t->ks; hit = 1; }
+        }
+        /* big grids (hundreds of tiles per CU round) are where the cost model is reliable and a measurement costly */
+        if (!hit && 2.0 * l->batch * l->out_h * l->out_w * (double)l->n * l->size * l->size * l->c > 40e9) continue;
+        if (!hit) {
+            c.tile_bm = c.tile_bn = c.ksplit = 0;
+            n = y2h_conv_candidates(&c, bm, bn, ks, 64);
+            if (n < 0) { e->timing = keep_timing; y2_fail("autotune of layer %d failed (%d): %s", i, n, y2h_last_error()); return -1; }
+            if (n == 0) continue;
+            for (a = 0; a < n; ++a) {
+                float ms = 0.f, m2 = 0.f;
+                int rep;
+                d->tile_bm = bm[a]; d->tile_bn = bn[a]; d->ksplit = ks[a];
+                for (rep = 0; rep < 2; ++rep) {            /* the first pass also sets the kernel's LDS attribute */
+                    if (enqueue_forward(net, e->d_in_nchw) != 0) { e->timing = keep_timing; return -1; }
+                    if (y2h_event_elapsed_ms(e->ev[i], e->ev[i + 1], &m2) != 0) { e->timing = keep_timing; y2_fail("autotune: %s", y2h_last_error()); return -1; }
+                    ms = (rep == 0 || m2 < ms) ? m2 : ms;
+                }
+                if (a == 0) ms *= 0.98f;                     /* the model's choice stays unless another wins by 2 % */
+                if (a == 0 || ms < best_ms) { best_ms = ms; best = a; }
+            }
+            d->tile_bm = bm[best]; d->tile_bn = bn[best]; d->ksplit = ks[best];
+            if (g_ntuned < (int)(sizeof g_tuned / sizeof g_tuned[0])) {
+                tune_entry *t = &g_tuned[g_ntuned++];
+                t->batch = c.batch; t->h = c.h; t->w = c.w; t->c = c.c; t->n = c.n; t->size = c.size; t->stride = c.stride;
+                t->pool = c.fuse_maxpool2; t->bm = d->tile_bm; t->bn = d->tile_bn; t->ks = d->ksplit;
+            }
+        }
+        conv_desc(net, i, &c, x, ldx);
+        d->kernel = y2h_conv_variant(&c, 0);
+        if (d->fused_pool) { snprintf(d->kname, sizeof d->kname, "%s+maxpool2", d->kernel); d->kernel = d->kname; }
+    }
+    e->timing = keep_timing;
+    HIPCALL(y2h_stream_sync(e->stream));
     return 0;
 }
 
@@ -778,21 +896,7 @@ int y2_engine_build(network *net)
         if (l->type == CONNECTED && !d->uses_mfma) d->kernel = "connected_ref";
         if (d->fused_pool) { snprintf(d->kname, sizeof d->kname, "%s+maxpool2", d->kernel); d->kernel = d->kname; }
     }
-    {   /* split-K scratch: the largest request of any conv layer */
-        size_t need = 0;
-        for (i = 0; i < net->n; ++i) {
-            y2h_conv c;
-            const float *x; int ldx;
-            size_t b;
-            if ((net->layers[i].type != CONVOLUTIONAL && net->layers[i].type != CONNECTED) || e->strict) continue;
-            input_view(net, i, &x, &ldx);
-            conv_desc(net, i, &c, x, ldx);
-            c.w_packed = (const float *)(uintptr_t)256;
-            b = y2h_conv_workspace_bytes(&c);
-            if (b > need) need = b;
-        }
-        if (need) { HIPCALL(y2h_malloc((void **)&e->d_ws, need)); e->ws_bytes = need; }
-    }
+    if (size_workspace(net) != 0) return -1;
     {   /* The packed arena is only valid for the layout it was filled for: a re-plan may move a layer between the
          * matrix-core and the reference-layout form, or switch the weights to half, without changing the total size.
          * Signature = FNV-1a over every per-layer offset and form flag. */
@@ -841,7 +945,12 @@ int y2_engine_build(network *net)
     e->built_batch = net->batch; e->built_w = net->w; e->built_h = net->h; e->built_strict = e->strict;
     e->built_fusion = e->fusion;
     e->built_half = e->half;
+    e->built_autotune = e->autotune;
     if (e->weights_dirty && !e->weights_external && upload_weights(net) != 0) return -1;
+    if (e->autotune && !e->strict) {
+        /* measured tile shapes: needs the buffers and the arena, so it runs last; the scratch is sized again afterwards */
+        if (autotune_layers(net) != 0 || size_workspace(net) != 0) { e->built = 0; return -1; }
+    }
     return 0;
 }
 
@@ -850,7 +959,8 @@ static int ensure_built(network *net)
     y2_engine *e = y2_engine_of(net);
     if (!e) { y2_fail("network has no engine (was it built by parse_network_cfg?)"); return -1; }
     if (!e->built || e->built_batch != net->batch || e->built_w != net->w || e->built_h != net->h ||
-        e->built_strict != e->strict || e->built_fusion != e->fusion || e->built_half != e->half) {
+        e->built_strict != e->strict || e->built_fusion != e->fusion || e->built_half != e->half ||
+        e->built_autotune != e->autotune) {
         if (y2_engine_build(net) != 0) return -1;
     } else {
         HIPCALL(y2h_set_device(e->device));
@@ -1137,6 +1247,12 @@ void y2_set_half(network *net, int on)
 {
     y2_engine *e = y2_engine_of(net);
     if (e) e->half = on ? 1 : 0;
+}
+
+void y2_set_autotune(network *net, int on)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (e) e->autotune = on ? 1 : 0;
 }
 
 void y2_set_fusion(network *net, int on)

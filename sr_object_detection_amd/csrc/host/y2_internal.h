@@ -28,6 +28,7 @@ typedef struct y2_ldev {
     int out_half;              /* this layer's activations are IEEE half (fp16 mode), out_ld counts halves */
     size_t off_alpha, off_beta; /* fp16 mode: folded batch-norm, y = act(acc*alpha + beta) */
     char kname[80];
+    int tile_bm, tile_bn, ksplit;   /* measured tile choice (y2_set_autotune), 0 = the host's cost model */
     /* region */
     float *d_anchors;
     int *d_tree_parent, *d_tree_gsize, *d_tree_goff, *d_map;
@@ -51,6 +52,7 @@ typedef struct y2_engine {
     int timing;
     int fusion, built_fusion;  /* conv+maxpool fusion enabled / state of the current plan */
     int half, built_half;      /* fp16 storage requested (y2_set_half) / state of the current plan */
+    int autotune, built_autotune; /* measure the conv tile shapes at plan time (y2_set_autotune) */
     int in_halo;               /* the NHWC copy of the input carries a zero border (2: the half NHWC4 form) */
     int in_halo_px;            /* its width in pixels: 1 for the 3x3 first-layer kernels, the padding for the stem kernel */
     /* hipGraph replay of the forward launch sequence (y2_set_graph): recorded for one input pointer, dropped with the plan */

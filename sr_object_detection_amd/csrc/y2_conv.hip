@@ -361,19 +361,35 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     }   // tile loop
 }
 
-// second pass of a split-K convolution: y[p][co] = epilogue(sum_s ws[s][p][co]), s ascending
+// second pass of a split-K convolution: y[p][co] = epilogue(sum_s ws[s][p][co]), s ascending.  With the fused 2x2
+// maxpool the GEMM rows are in pool-major order (row 4q + t = corner t of window q): the pooled value is the max over
+// the four epilogue results, exactly what the unsplit kernel's epilogue computes.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK a)
 {
-    const long total = (long)a.npix * a.Cout;
+    const long rows = a.pool ? (long)a.npix >> 2 : (long)a.npix;
+    const long total = rows * a.Cout, slab = (long)a.npix * a.Cout;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int co = (int)(idx % a.Cout);
         const long p = idx / a.Cout;
-        float sum = a.ws[idx];
-        for (int s = 1; s < a.ksplit; ++s) sum += a.ws[(size_t)s * total + idx];
         float mean = 0.f, scale = 1.f;
         double rinv = 1.0;
         if (a.bn) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
-        a.y[(size_t)p * a.ldy + co] = epilogue_f32(sum, a.bn, mean, rinv, scale, a.bias[co], a.act);
+        const float bias = a.bias[co];
+        if (a.pool) {
+            float m = 0.f;
+            for (int t = 0; t < 4; ++t) {
+                const long off = (4 * p + t) * a.Cout + co;
+                float sum = a.ws[off];
+                for (int s = 1; s < a.ksplit; ++s) sum += a.ws[(size_t)s * slab + off];
+                const float v = epilogue_f32(sum, a.bn, mean, rinv, scale, bias, a.act);
+                m = (t == 0 || v > m) ? v : m;
+            }
+            a.y[(size_t)p * a.ldy + co] = m;
+            continue;
+        }
+        float sum = a.ws[idx];
+        for (int s = 1; s < a.ksplit; ++s) sum += a.ws[(size_t)s * slab + idx];
+        a.y[(size_t)p * a.ldy + co] = epilogue_f32(sum, a.bn, mean, rinv, scale, bias, a.act);
     }
 }
 
@@ -817,7 +833,7 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
     const long npix = (long)d->batch * d->out_h * d->out_w;
     const int nk = d->size * d->size * (d->c / bk);
     const int CUS = 256;
-    int force_bm = 0, force_bn = 0, force_split = 0;
+    int force_bm = d->tile_bm, force_bn = d->tile_bn, force_split = d->ksplit;      // a tuned descriptor (y2h_conv_tune)
     if (const char *f = getenv("Y2_CONV_TILE")) sscanf(f, "%dx%d", &force_bm, &force_bn);
     if (const char *f = getenv("Y2_CONV_KSPLIT")) force_split = atoi(f);
     Variant *best = nullptr;
@@ -830,13 +846,13 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
         const int bpc = variant_bpc(v);
         // split only grids that cannot give every CU one workgroup, keep >= 8 slices per range
         int ksplit = 1;
-        if (!d->fuse_maxpool2 && tiles < CUS && nk >= 16) {
+        if (tiles < CUS && nk >= 16) {
             ksplit = (int)((long)CUS * bpc / tiles);
             if (ksplit > nk / 8) ksplit = nk / 8;
             if (ksplit > 32) ksplit = 32;
             if (ksplit < 1) ksplit = 1;
         }
-        if (force_split > 0 && !d->fuse_maxpool2) ksplit = force_split <= nk ? force_split : nk;
+        if (force_split > 0) ksplit = force_split <= nk ? force_split : nk;
         const long blocks = tiles * ksplit;
         long per_cu;
         if (blocks <= (long)CUS * bpc) per_cu = (blocks + CUS - 1) / CUS;
@@ -865,6 +881,95 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
     }
     if (ksplit_out) *ksplit_out = best_split;
     return best;
+}
+
+// ---------------------------------------------------------------------------
+// Tile autotuning: the cost model above ranks tile shapes from grid arithmetic; on small grids (batch 1..8) its
+// error is 10-40 % of a layer (profiles/r02_notes.md), so a plan may instead MEASURE each shape once.
+// ---------------------------------------------------------------------------
+// the (tile, K-split) combinations worth measuring for a descriptor; entry 0 is the cost model's own choice
+extern "C" int y2h_conv_candidates(const y2h_conv *d, int *bm, int *bn, int *ks, int max)
+{
+    if (!d || !bm || !bn || !ks || max < 1) return Y2H_EINVAL;
+    if (d->x_f16 || d->x_halo != 0 || !mfma_ok(d)) return 0;
+    const int bk = (d->c % 32 == 0) ? 32 : 16;
+    const int nk = d->size * d->size * (d->c / bk);
+    y2h_conv t = *d;
+    t.tile_bm = t.tile_bn = t.ksplit = 0;
+    int model_split = 1, n = 0;
+    Variant *mv = pick_variant(&t, &model_split);
+    if (!mv) return 0;
+    bm[n] = mv->bm; bn[n] = mv->bn; ks[n] = model_split; ++n;
+    for (Variant &v : g_variants) {
+        if (v.bk != bk || v.ks != d->size) continue;
+        y2h_conv q = t; q.tile_bm = v.bm; q.tile_bn = v.bn;
+        int own = 1;
+        if (!pick_variant(&q, &own)) continue;
+        const int splits[5] = {1, model_split, model_split * 2, model_split / 2, own};
+        for (int a = 0; a < 5; ++a) {
+            const int k = splits[a];
+            bool dup = k < 1 || k > nk;
+            for (int b = 0; b < n && !dup; ++b) dup = bm[b] == v.bm && bn[b] == v.bn && ks[b] == k;
+            if (dup || n >= max) continue;
+            if (k > 1 && (size_t)k * d->batch * d->out_h * d->out_w * d->n * sizeof(float) > ((size_t)256 << 20)) continue;
+            bm[n] = v.bm; bn[n] = v.bn; ks[n] = k; ++n;
+        }
+    }
+    return n;
+}
+
+extern "C" int y2h_conv_tune(y2h_conv *d, int reps, y2h_stream s)
+{
+    if (!d || reps < 1) return Y2H_EINVAL;
+    if (d->x_f16 || d->x_halo != 0 || !mfma_ok(d)) return 0;
+    const int bk = (d->c % 32 == 0) ? 32 : 16;
+    const int nk = d->size * d->size * (d->c / bk);
+    y2h_conv t = *d;
+    t.tile_bm = t.tile_bn = t.ksplit = 0;
+    int model_split = 1;
+    Variant *mv = pick_variant(&t, &model_split);
+    if (!mv) return 0;
+    hipEvent_t e0, e1;
+    Y2H_CHECK(hipEventCreate(&e0));
+    Y2H_CHECK(hipEventCreate(&e1));
+    float best_ms = 1e30f;
+    int best_bm = mv->bm, best_bn = mv->bn, best_split = model_split, tried = 0, rc = Y2H_OK;
+    for (Variant &v : g_variants) {
+        if (v.bk != bk || v.ks != d->size) continue;
+        // K-splits worth a try: none, the model's, and its neighbours
+        int splits[5] = {1, model_split, model_split * 2, model_split / 2, 0}, ns = 4;
+        {   // what the model would do with THIS tile
+            y2h_conv q = t; q.tile_bm = v.bm; q.tile_bn = v.bn;
+            int ks = 1;
+            if (pick_variant(&q, &ks)) splits[ns++] = ks;
+        }
+        for (int a = 0; a < ns && rc == Y2H_OK; ++a) {
+            const int ks = splits[a];
+            bool dup = ks < 1 || ks > nk;
+            for (int b = 0; b < a; ++b) dup = dup || splits[b] == ks;
+            if (dup) continue;
+            if (ks > 1 && (!d->ws || (size_t)ks * d->batch * d->out_h * d->out_w * d->n * sizeof(float) > d->ws_bytes)) continue;
+            y2h_conv q = t;
+            q.tile_bm = v.bm; q.tile_bn = v.bn; q.ksplit = ks;
+            if ((rc = y2h_conv_forward(&q, 0, s)) != Y2H_OK) break;            // warm-up (and LDS attribute)
+            if (hipEventRecord(e0, S(s)) != hipSuccess) { rc = Y2H_EHIP; break; }
+            for (int r = 0; r < reps && rc == Y2H_OK; ++r) rc = y2h_conv_forward(&q, 0, s);
+            if (rc != Y2H_OK) break;
+            float ms = 0.f;
+            if (hipEventRecord(e1, S(s)) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = Y2H_EHIP; break; }
+            ++tried;
+            // a different tile must win by 2 % (timer noise), otherwise the model's choice stays
+            const bool is_model = (v.bm == mv->bm && v.bn == mv->bn && ks == model_split);
+            if (ms * (is_model ? 0.98f : 1.0f) < best_ms) { best_ms = ms * (is_model ? 0.98f : 1.0f); best_bm = v.bm; best_bn = v.bn; best_split = ks; }
+        }
+        if (rc != Y2H_OK) break;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != Y2H_OK) return rc;
+    d->tile_bm = best_bm; d->tile_bn = best_bn; d->ksplit = best_split;
+    return tried;
 }
 
 extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)

@@ -173,6 +173,7 @@ def lib():
     L.y2_set_strict.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_half.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_fusion.argtypes = [C.POINTER(CNetwork), C.c_int]
+    L.y2_set_autotune.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_graph.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_timing.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_layer_times_ms.argtypes = [CNetwork, C.c_void_p, C.c_int]
@@ -392,6 +393,10 @@ class Network:
     def set_half(self, on: bool) -> None:
         """fp16 storage / fp32 accumulate (engine extension, include/sr_yolo2.h y2_set_half)."""
         lib().y2_set_half(C.byref(self.net), 1 if on else 0)
+
+    def set_autotune(self, on: bool) -> None:
+        """measure the conv tile shapes at plan time instead of modelling them (include/sr_yolo2.h y2_set_autotune)"""
+        lib().y2_set_autotune(C.byref(self.net), 1 if on else 0)
 
     def set_fusion(self, on: bool) -> None:
         lib().y2_set_fusion(C.byref(self.net), 1 if on else 0)

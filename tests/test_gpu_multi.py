@@ -111,7 +111,7 @@ def test_bench_launches_two_ranks_itself_and_rank1_matches_a_single_process(work
         env.pop(k, None)
     dump = str(tmp_path / "dets")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "yolo416_b8", "--steps", "3",
-                        "--warmup", "1", "--cpu-iters", "0", "--host-input", "off", "--dump-dets", dump],
+                        "--warmup", "1", "--cpu-iters", "0", "--host-input", "off", "--autotune", "0", "--dump-dets", dump],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])

@@ -298,3 +298,38 @@ def test_three_frame_mean_matches_oracle(oracle, workdir):
             assert [float(d[key]) for key in "xywh"] == [float(v) for v in boxes[i]]
     net.free()
     on.close()
+
+
+def test_autotuned_plan_matches_reference_and_is_remembered(workdir):
+    """y2_set_autotune: every fp32 matrix-core convolution times its tile shapes at plan time.  The tile never changes a
+    result bit; a measured K-split may differ from the modelled one, so the comparison with the reference golden keeps
+    the 1e-4 bar.  A second network of the same shapes re-uses the measured choices."""
+    g = load_golden("yolo_416_b1")
+    cfg, wts, x = materialize(workdir, "yolo", 416, 1, int(g["seed"]), float(g["head_gain"]))
+    nets = []
+    for k in range(2):
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        net.set_autotune(True)
+        out = net.network_predict(x)
+        assert np.abs(out - g["out"]).max() < TOL
+        nets.append([net.layer_kernel(i) for i in range(net.n)])
+        dets, counts = net.detect_resident(float(g["thresh"]), float(g["nms"]))
+        total, classes = net.last.w * net.last.h * net.last.n, net.last.classes
+        gpost = dense_from_sparse(g["post_idx_0"], g["post_val_0"], total, classes)
+        assert int(counts[0]) == int((gpost.max(axis=1) > float(g["thresh"])).sum())
+        net.free()
+    assert nets[0] == nets[1]                      # remembered per shape, not measured again
+    assert all(n.startswith(("conv_mfma_f32_", "conv_first_")) for n in nets[0] if n.startswith("conv"))
+
+
+def test_batch1_pooled_layers_are_k_split(workdir):
+    """batch-1 inference (the Kinect caller): a conv + maxpool pair on a grid too small for 256 CUs is cut along K like
+    any other layer, and still equals the unfused plan"""
+    g = load_golden("tiny_yolo_voc_416_b1")
+    cfg, wts, x = materialize(workdir, "tiny-yolo-voc", 416, 1, int(g["seed"]), float(g["head_gain"]))
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    out = net.network_predict(x)
+    assert np.abs(out - g["out"]).max() < TOL
+    net.free()

@@ -88,14 +88,16 @@ def test_f32_tile_is_exact(oracle, workdir, monkeypatch, bk, tile, ksize, pool):
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
 @pytest.mark.parametrize("tile", F32_TILES_BK32, ids=lambda t: "%dx%d" % t)
-def test_f32_tile_split_k_is_exact(oracle, workdir, monkeypatch, tile):
-    """the K loop of a tile cut into three uneven ranges (27 slices of a 3x3x96 filter -> 9/9/9; 18 -> 6/6/6 at BK 32),
-    partial sums through the workspace, splitk_reduce_kernel"""
+def test_f32_tile_split_k_is_exact(oracle, workdir, monkeypatch, tile, pool):
+    """the K loop of a tile cut into four uneven ranges (27 slices of a 3x3x96 filter -> 6/7/7/7), partial sums through
+    the workspace, splitk_reduce_kernel -- which also takes the fused 2x2 maxpool (pool-major GEMM rows: max over the four
+    epilogue results of a window)"""
     bm, bn = tile
-    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=96, filters=bn + 24, ksize=3, size=19, batch=3, tile=tile,
-                             pool=False, ksplit=4, seed=5000 + bm + bn)
-    assert name == "conv_mfma_f32_%dx%dx32_k3" % (bm, bn), name
+    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=96, filters=bn + 24, ksize=3, size=20 if pool else 19, batch=3,
+                             tile=tile, pool=pool, ksplit=4, seed=5000 + bm + bn + pool)
+    assert name == "conv_mfma_f32_%dx%dx32_k3%s" % (bm, bn, "+maxpool2" if pool else ""), name
     assert np.array_equal(out, ref)
 
 
