@@ -68,8 +68,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // [2 buffers][BM + BN rows][LS]
+    // [2 buffers][BM + BN rows][LS]  (+ [waves][16][ES] epilogue scratch in the 8-wave tiles)
     constexpr int BUF = (BM + BN) * LS;
+    // 8-wave tiles (one workgroup per CU, LDS to spare): outputs leave as 16-byte stores through a wave-private LDS
+    // transpose.  A lane of the accumulator layout owns ONE filter of 16 pixels -- sixteen 4-byte stores per 32x32 tile,
+    // 96 per lane and tile, each with its own 64-bit address; transposed, a lane stores 4 consecutive filters of a pixel.
+    constexpr bool VST = (WM * WN == 8);
+    constexpr int ES = 36;                // scratch row stride (floats): 32 filters + 16 B
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // per-tile prologue latency nor a second launch wave is exposed.
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.ybytes, 0x00020000);
 
     // staging role of this thread: chunk `sc` of rows `sr + q*RP`
     const int sc = t % CH, sr = t / CH;
@@ -305,8 +311,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // epilogue: lane holds column (cout) li of each 32x32 tile and 16 rows (pixels)
     // (`bn` and `act` are uniform, but tested per output value they are real branches -- 1439 s_cbranch in the 192x256
     // instantiation; the common batch-norm + leaky case is compiled with both as constants)
-    auto epilogue_pass = [&](auto MODEC) {
-        constexpr int MODE = decltype(MODEC)::value;        // 0 run-time bn / act, 1 batch-norm + leaky, 2 batch-norm + linear
+    auto epilogue_pass = [&](auto MODEC, auto VSTC) {
+        constexpr int MODE = decltype(MODEC)::value;
+        constexpr bool VS = decltype(VSTC)::value;            // 16-byte stores through the LDS transpose        // 0 run-time bn / act, 1 batch-norm + leaky, 2 batch-norm + linear
         const bool BN_ = MODE ? true : (bool)a.bn;
         const int ACT_ = MODE == 1 ? (int)Y2H_ACT_LEAKY : MODE == 2 ? (int)Y2H_ACT_LINEAR : a.act;
 #pragma unroll
@@ -332,6 +339,50 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                     }
                     continue;
                 }
+                if constexpr (VS) {
+                    // LDS operations of one wave execute in order, and the scratch is this wave's own: no barrier.
+                    // Stores go through the buffer descriptor of y with 32-bit offsets (rows past the end and filters
+                    // past Cout get an out-of-range offset: the store is dropped, no exec masking, no 64-bit address math
+                    // -- the scalar form spills 127 registers of hoisted 64-bit addresses in this tile shape).
+                    float *es = smem + 2 * BUF + wv * (16 * ES);
+                    const int cb = n0 + wn * (BN / WN) + j * 32;          // first filter of this 32-wide tile
+                    const int pb = p0 + wm * (BM / WM) + i * 32;          // first GEMM row of this tile
+                    const int rrow = lane >> 3, rch = (lane & 7) * 4;     // read side: row 0..7 (+8), filters rch..rch+3
+                    const bool fok = cb + rch < a.Cout;
+                    if (a.pool) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float m = epilogue_f32(acc[i][j][4 * g], BN_, mean, rinv, scale, bias, ACT_);
+#pragma unroll
+                            for (int t = 1; t < 4; ++t) {
+                                const float v = epilogue_f32(acc[i][j][4 * g + t], BN_, mean, rinv, scale, bias, ACT_);
+                                m = (v > m) ? v : m;
+                            }
+                            es[(2 * g + lh) * ES + li] = m;               // pooled row (pb + 8g + 4lh) / 4 - pb / 4
+                        }
+                        const u32x4 v = *(const u32x4 *)&es[rrow * ES + rch];
+                        const int prow_ = (pb >> 2) + rrow;
+                        const unsigned off = (fok && 4 * prow_ < a.npix) ? ((unsigned)prow_ * (unsigned)a.ldy + (unsigned)(cb + rch)) * 4u : 0xffffffffu;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
+                    } else {
+                        const unsigned base = ((unsigned)(pb + rrow) * (unsigned)a.ldy + (unsigned)(cb + rch)) * 4u;
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {                  // rows 0..15, then 16..31 of the tile
+#pragma unroll
+                            for (int r = 0; r < 8; ++r)
+                                es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + li] =
+                                    epilogue_f32(acc[i][j][8 * h2 + r], BN_, mean, rinv, scale, bias, ACT_);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const u32x4 v = *(const u32x4 *)&es[(rrow + 8 * u) * ES + rch];
+                                const int p = pb + 16 * h2 + rrow + 8 * u;
+                                const unsigned off = (fok && p < a.npix) ? base + (unsigned)(16 * h2 + 8 * u) * (unsigned)a.ldy * 4u : 0xffffffffu;
+                                __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // one tile at a time: interleaved, the six tiles' temporaries spill
+                } else {
                 if (a.pool) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -342,22 +393,31 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                             const float v = epilogue_f32(acc[i][j][4 * g + t], BN_, mean, rinv, scale, bias, ACT_);
                             m = (v > m) ? v : m;
                         }
-                        if (cok && r0 < a.npix) a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
+                        // buffer store, 32-bit offset, out-of-range = dropped (no exec masking, no 64-bit address per store)
+                        const unsigned off = (cok && r0 < a.npix) ? ((unsigned)(r0 >> 2) * (unsigned)a.ldy + (unsigned)co) * 4u : 0xffffffffu;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), yr, off, 0, 0);
                     }
                 } else {
+                    const unsigned base = ((unsigned)prow * (unsigned)a.ldy + (unsigned)co) * 4u;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int p = prow + (r & 3) + 8 * (r >> 2);
-                        if (cok && p < a.npix)
-                            a.y[(size_t)p * a.ldy + co] = epilogue_f32(acc[i][j][r], BN_, mean, rinv, scale, bias, ACT_);
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        const float v = epilogue_f32(acc[i][j][r], BN_, mean, rinv, scale, bias, ACT_);
+                        const unsigned off = (cok && prow + dr < a.npix) ? base + (unsigned)dr * (unsigned)a.ldy * 4u : 0xffffffffu;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off, 0, 0);
                     }
+                }
                 }
             }
         }
     };
-    if (a.bn && a.act == Y2H_ACT_LEAKY) epilogue_pass(std::integral_constant<int, 1>{});
-    else if (a.bn && a.act == Y2H_ACT_LINEAR) epilogue_pass(std::integral_constant<int, 2>{});     // resnet's 1x1 expansions
-    else epilogue_pass(std::integral_constant<int, 0>{});
+    if (VST && a.vec_store && a.bn && a.act == Y2H_ACT_LEAKY) {        // (every conv of the target cfgs but the last)
+        epilogue_pass(std::integral_constant<int, 1>{}, std::true_type{});
+    } else {
+        if (a.bn && a.act == Y2H_ACT_LEAKY) epilogue_pass(std::integral_constant<int, 1>{}, std::false_type{});
+        else if (a.bn && a.act == Y2H_ACT_LINEAR) epilogue_pass(std::integral_constant<int, 2>{}, std::false_type{});     // resnet's 1x1 expansions
+        else epilogue_pass(std::integral_constant<int, 0>{}, std::false_type{});
+    }
     }   // tile loop
 }
 
@@ -768,7 +828,7 @@ struct Variant {
 
 #define VAR(BM, BN, BK, KS, WM, WN)                                                             \
     { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
-      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float), WM * WN * 64, {false} }
+      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false} }
 
 #ifndef Y2_PIPE
 #define Y2_PIPE true
@@ -804,7 +864,8 @@ static bool mfma_ok(const y2h_conv *d)
     if (((uintptr_t)d->x | (uintptr_t)d->w_packed) % 16 != 0) return false;
     const double xbytes = (double)d->batch * d->h * d->w * d->ldx * 4.0;
     const double wbytes = (double)d->n * d->size * d->size * d->c * 4.0;
-    if (xbytes >= 4294967000.0 || wbytes >= 4294967000.0) return false;   // 32-bit buffer offsets
+    const double ybytes = (double)d->batch * d->out_h * d->out_w * (d->fuse_maxpool2 ? 0.25 : 1.0) * d->ldy * 4.0;
+    if (xbytes >= 4294967000.0 || wbytes >= 4294967000.0 || ybytes >= 4294967000.0) return false;   // 32-bit buffer offsets
     return d->w_packed != nullptr;
 }
 
@@ -1130,6 +1191,11 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         a.npix = d->batch * d->out_h * d->out_w;
         a.xbytes = (unsigned)((size_t)d->batch * d->h * d->w * d->ldx * 4);
         a.wbytes = (unsigned)((size_t)d->n * a.K * 4);
+        // 16-byte output stores (8-wave tiles): a pixel's filters must start on 16 bytes
+        {
+            a.ybytes = (unsigned)((size_t)(d->fuse_maxpool2 ? a.npix / 4 : a.npix) * d->ldy * 4);        // < 4 GB: mfma_ok
+            a.vec_store = d->ldy % 4 == 0 && d->n % 4 == 0 && ((uintptr_t)d->y % 16) == 0 && ksplit == 1 && !getenv("Y2_F32_SCALAR_STORES");
+        }
         a.tiles_n = (d->n + v->bn - 1) / v->bn;
         const long tiles_m = ((long)a.npix + v->bm - 1) / v->bm;
         int dev = 0;

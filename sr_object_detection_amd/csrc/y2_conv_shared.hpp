@@ -26,6 +26,7 @@ struct ConvK {
     int pool;          // 1: a 2x2 stride-2 maxpool is fused behind the activation (see pool_pixel)
     int bn, act;
     unsigned xbytes, wbytes;
+    unsigned ybytes;   // fp32 8-wave tiles with vec_store: byte size of the output buffer from a.y on (buffer stores)
     int tiles_n;
     int ntiles;        // tiles_m * tiles_n * ksplit work items; workgroups walk them with stride gridDim.x
     int ksplit;        // >= 1: number of K ranges each output tile is cut into (split-K)

@@ -25,7 +25,7 @@ def load(d, tag):
         k = int(x["Dispatch_Id"])
         if k in rows:
             rows[k]["us"] = (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3
-    ids = [k for k in rows if rows[k]["name"].startswith("nchw_to_nhwc")]
+    ids = [k for k in rows if "nchw_to_nhwc" in rows[k]["name"]]
     want_conv = not OTHER
     return [rows[k] for k in rows if k >= ids[-1] and (("conv" in rows[k]["name"]) == want_conv)]
 
