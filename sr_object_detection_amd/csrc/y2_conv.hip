@@ -209,6 +209,27 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     store_slice(0);
     __syncthreads();
 
+    // EB ("early barrier", BK = 32 tiles): the slice fetched in this K-step is written to the other LDS buffer under the
+    // SECOND-TO-LAST MFMA group and the workgroup barrier follows that group; the last group then multiplies from
+    // fragments already in registers while the first fragments of the NEXT K-step are read from the buffer the barrier
+    // has just published -- a K-step boundary no longer exposes an LDS read latency with the matrix pipe idle.  Still
+    // one barrier per K-step: every read of the current buffer is issued (and, by the barrier's lgkmcnt(0), returned)
+    // before the barrier, so the buffer may be overwritten one step later without a second one.
+#ifdef Y2_NO_EARLYB
+    constexpr bool EB = false;
+#else
+    constexpr bool EB = PIPE && BK >= 32;
+#endif
+    f32x4 af[2][TM], bf[2][TN];      // operand fragments, two register sets (EB: live across K-steps and tiles)
+    if (EB) {
+        const float *As0 = smem + (wm * (BM / WM) + li) * LS + lh * 4;
+        const float *Bs0 = smem + BM * LS + (wn * (BN / WN) + li) * LS + lh * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *(const f32x4 *)&As0[i * 32 * LS];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *(const f32x4 *)&Bs0[j * 32 * LS];
+    }
+
     // One K-step = BK/8 groups of 4*TM*TN MFMAs.  Software pipeline (PIPE): the operand fragments
     // of group g+1 are read from LDS while group g multiplies (two register sets), the global
     // loads of the next slice are issued under group 0 and written to the other LDS buffer
@@ -258,11 +279,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             }
             store_slice(cur ^ 1);
         } else {
-            f32x4 af[2][TM], bf[2][TN];
+            if (!EB) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = *(const f32x4 *)&As[i * 32 * LS];
+                for (int i = 0; i < TM; ++i) af[0][i] = *(const f32x4 *)&As[i * 32 * LS];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = *(const f32x4 *)&Bs[j * 32 * LS];
+                for (int j = 0; j < TN; ++j) bf[0][j] = *(const f32x4 *)&Bs[j * 32 * LS];
+            }
+            constexpr int SG = EB ? NG - 2 : NG - 1;      // group under which the fetched slice is written to LDS
 #pragma unroll
             for (int kg = 0; kg < NG; ++kg) {
                 const int c = kg & 1, n = c ^ 1;
@@ -271,9 +294,17 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                     for (int i = 0; i < TM; ++i) af[n][i] = *(const f32x4 *)&As[i * 32 * LS + (kg + 1) * 8];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bf[n][j] = *(const f32x4 *)&Bs[j * 32 * LS + (kg + 1) * 8];
+                } else if (EB) {
+                    // group 0 of the next K-step, from the buffer published by the barrier behind group NG-2
+                    const float *An = smem + (cur ^ 1) * BUF + (wm * (BM / WM) + li) * LS + lh * 4;
+                    const float *Bn = smem + (cur ^ 1) * BUF + BM * LS + (wn * (BN / WN) + li) * LS + lh * 4;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[n][i] = *(const f32x4 *)&An[i * 32 * LS];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[n][j] = *(const f32x4 *)&Bn[j * 32 * LS];
                 }
                 if (kg == 0) load_slice();
-                if (kg == NG - 1) store_slice(cur ^ 1);
+                if (kg == SG) store_slice(cur ^ 1);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -284,7 +315,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                 // issue order inside the group: one MFMA first (the pipe is busy from here on), then the
                 // fragment reads of the next group, then the staging work one piece per MFMA
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (kg + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                if (kg + 1 < NG || EB) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
                 if (kg == 0) {
 #pragma unroll
                     for (int q = 0; q < PA + PB; ++q) {
@@ -293,7 +324,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
-                if (kg == NG - 1) {
+                if (kg == SG) {
 #pragma unroll
                     for (int q = 0; q < PA + PB; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -301,9 +332,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (EB && kg == SG) __syncthreads();
             }
         }
-        __syncthreads();
+        if (!EB || !PIPE) __syncthreads();
         cur ^= 1;
     }
     __builtin_amdgcn_s_setprio(0);
