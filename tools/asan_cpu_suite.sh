@@ -8,12 +8,12 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$(mktemp -d)
 C=$ROOT/sr_object_detection_amd/csrc
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g -fPIC"
-for f in y2_cfg y2_weights y2_engine y2_detect y2_eval; do
+for f in y2_cfg y2_weights y2_engine y2_detect y2_eval y2_comm y2_feed; do
     gcc $SAN -ffp-contract=off -std=gnu11 -I$ROOT/include -I$C/host -c $C/host/$f.c -o $OUT/$f.o
 done
 g++ $SAN -std=c++17 -I$ROOT/include -I$C/host -c $C/yolo_v2_class.cpp -o $OUT/yolo_v2_class.o
 g++ -shared -fPIC -fsanitize=address,undefined -o $OUT/libsr_yolo2.so $C/build/y2_runtime.o $C/build/y2_conv.o $C/build/y2_conv_f16.o \
-    $C/build/y2_layers.o $C/build/y2_layers_f16.o $C/build/y2_detect_dev.o $C/build/y2_image.o $OUT/*.o -L/opt/rocm/lib -lamdhip64 -lm -lstdc++
+    $C/build/y2_layers.o $C/build/y2_layers_f16.o $C/build/y2_detect_dev.o $C/build/y2_image.o $OUT/*.o -L/opt/rocm/lib -lamdhip64 -lm -lstdc++ -ldl
 cp $ROOT/oracle/liby2oracle.so $OUT/liby2oracle.orig
 trap 'cp $OUT/liby2oracle.orig $ROOT/oracle/liby2oracle.so; touch $ROOT/oracle/liby2oracle.so' EXIT
 gcc $SAN -fopenmp -ffp-contract=off -shared -o $ROOT/oracle/liby2oracle.so $ROOT/oracle/y2_oracle.c -lm
