@@ -384,12 +384,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                     if (a.pool) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            float m = epilogue_f32(acc[i][j][4 * g], BN_, mean, rinv, scale, bias, ACT_);
-#pragma unroll
-                            for (int t = 1; t < 4; ++t) {
-                                const float v = epilogue_f32(acc[i][j][4 * g + t], BN_, mean, rinv, scale, bias, ACT_);
-                                m = (v > m) ? v : m;
-                            }
+                            const float m = epilogue_f32(pool_pick(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3],
+                                                                 !BN_ || scale >= 0.f), BN_, mean, rinv, scale, bias, ACT_);
                             es[(2 * g + lh) * ES + li] = m;               // pooled row (pb + 8g + 4lh) / 4 - pb / 4
                         }
                         const u32x4 v = *(const u32x4 *)&es[rrow * ES + rch];
@@ -419,12 +415,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int r0 = prow + 8 * g;              // first of the window's four rows
-                        float m = epilogue_f32(acc[i][j][4 * g], BN_, mean, rinv, scale, bias, ACT_);
-#pragma unroll
-                        for (int t = 1; t < 4; ++t) {
-                            const float v = epilogue_f32(acc[i][j][4 * g + t], BN_, mean, rinv, scale, bias, ACT_);
-                            m = (v > m) ? v : m;
-                        }
+                        const float m = epilogue_f32(pool_pick(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3],
+                                                                 !BN_ || scale >= 0.f), BN_, mean, rinv, scale, bias, ACT_);
                         // buffer store, 32-bit offset, out-of-range = dropped (no exec masking, no 64-bit address per store)
                         const unsigned off = (cok && r0 < a.npix) ? ((unsigned)(r0 >> 2) * (unsigned)a.ldy + (unsigned)co) * 4u : 0xffffffffu;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), yr, off, 0, 0);
@@ -468,15 +460,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK a)
         if (a.bn) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
         const float bias = a.bias[co];
         if (a.pool) {
-            float m = 0.f;
+            float sums[4];
             for (int t = 0; t < 4; ++t) {
                 const long off = (4 * p + t) * a.Cout + co;
                 float sum = a.ws[off];
                 for (int s = 1; s < a.ksplit; ++s) sum += a.ws[(size_t)s * slab + off];
-                const float v = epilogue_f32(sum, a.bn, mean, rinv, scale, bias, a.act);
-                m = (t == 0 || v > m) ? v : m;
+                sums[t] = sum;
             }
-            a.y[(size_t)p * a.ldy + co] = m;
+            a.y[(size_t)p * a.ldy + co] = epilogue_f32(pool_pick(sums[0], sums[1], sums[2], sums[3], !a.bn || scale >= 0.f), a.bn, mean,
+                                                      rinv, scale, bias, a.act);
             continue;
         }
         float sum = a.ws[idx];
@@ -583,12 +575,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const long r0 = prow + 8 * g;
-                    float m = epilogue_f32(acc[j][4 * g], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
-#pragma unroll
-                    for (int t = 1; t < 4; ++t) {
-                        const float v = epilogue_f32(acc[j][4 * g + t], a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
-                        m = (v > m) ? v : m;
-                    }
+                    const float m = epilogue_f32(pool_pick(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3], !a.bn || scale[j] >= 0.f),
+                                                 a.bn, mean[j], rinv[j], scale[j], bias[j], a.act);
                     if (co < a.Cout && r0 < a.npix) {
                         if (a.y_f16) ((_Float16 *)a.y)[(size_t)(r0 >> 2) * a.ldy + co] = (_Float16)m;
                         else a.y[(size_t)(r0 >> 2) * a.ldy + co] = m;
@@ -659,12 +647,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const long r0 = prow + 8 * g;
-                        float m = epilogue_f32(acc[j][4 * g], true, mean[j], rinv[j], scale[j], bias[j], Y2H_ACT_LEAKY);
-#pragma unroll
-                        for (int t = 1; t < 4; ++t) {
-                            const float v = epilogue_f32(acc[j][4 * g + t], true, mean[j], rinv[j], scale[j], bias[j], Y2H_ACT_LEAKY);
-                            m = (v > m) ? v : m;
-                        }
+                        const float m = epilogue_f32(pool_pick(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3], scale[j] >= 0.f),
+                                                     true, mean[j], rinv[j], scale[j], bias[j], Y2H_ACT_LEAKY);
                         put((unsigned long)(r0 >> 2), co, m, co < a.Cout && r0 < a.npix);
                     }
                 } else {
@@ -683,7 +667,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
 #pragma unroll
             for (int t = 0; t < 14 * NT; ++t) {          // one MFMA, then a share of the epilogue's VALU work and a store
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, POOL ? 14 : 13, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, POOL ? 7 : 13, 0);
                 __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
             }
         };

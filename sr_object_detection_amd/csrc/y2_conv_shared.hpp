@@ -71,6 +71,19 @@ __device__ __forceinline__ float epilogue_f32(float v, bool bn, float mean, doub
 #endif
 }
 
+// Fused conv + maxpool: the epilogue is a MONOTONE function of the accumulator -- every step (x - mean, * rinv > 0 in
+// double, * scale, + bias, leaky / linear / logistic / relu) is monotone and every rounding is monotone; the whole is
+// non-decreasing when scale >= 0 (or without batch-norm) and non-increasing otherwise.  So
+//     max_t epilogue(acc_t) == epilogue(max_t acc_t)      (scale >= 0),      == epilogue(min_t acc_t)     (scale < 0)
+// EXACTLY, and a pooling window costs one epilogue evaluation instead of four (the first layer was bound by this
+// arithmetic: 378 M double-precision evaluations per 32 frames of 608x608).
+__device__ __forceinline__ float pool_pick(float a0, float a1, float a2, float a3, bool increasing)
+{
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(a0, a1), __builtin_fmaxf(a2, a3));
+    const float mn = __builtin_fminf(__builtin_fminf(a0, a1), __builtin_fminf(a2, a3));
+    return increasing ? mx : mn;
+}
+
 // fp16 path: BN folded into one fma on the fp32 accumulator (alpha = scale/(sqrt(var)+1e-6), beta = bias - mean*alpha),
 // fp32 activation.  There is no reference arithmetic to mirror here: the reference has no half path.
 __device__ __forceinline__ float epilogue_fast(float v, float alpha, float beta, int act)

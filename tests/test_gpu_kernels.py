@@ -172,8 +172,9 @@ def test_resize_image_matches_oracle_bitwise(oracle):
         assert np.array_equal(darknet.resize_image(x, w, h), oracle.resize_image(x, w, h))
 
 
-def _small_int_conv_case(workdir, spec, size, batch, seed):
-    """cfg + integer-valued weights/inputs so that every fp32 partial sum is exact in any order."""
+def _small_int_conv_case(workdir, spec, size, batch, seed, neg_scale=False):
+    """cfg + integer-valued weights/inputs so that every fp32 partial sum is exact in any order.
+    neg_scale: batch-norm scales alternate +1, -1.5 (a negative scale turns the epilogue into a DEcreasing function)."""
     import os
     import struct
     layers = zoo.resolve(spec, size)
@@ -190,7 +191,10 @@ def _small_int_conv_case(workdir, spec, size, batch, seed):
             s += 1
             f.write(np.round(synth.uniform(s, n, -2, 2)).astype(np.float32).tobytes())          # biases
             if l["batch_normalize"]:
-                f.write(np.full(n, 1, np.float32).tobytes())                                      # scales
+                sc = np.full(n, 1, np.float32)
+                if neg_scale:
+                    sc[1::2] = -1.5
+                f.write(sc.tobytes())                                                             # scales
                 f.write(np.round(synth.uniform(s + 100, n, -2, 2)).astype(np.float32).tobytes())  # mean
                 f.write(np.full(n, 1, np.float32).tobytes())                                      # variance
             f.write(np.round(synth.uniform(s + 200, n * K, -1.49, 1.49)).astype(np.float32).tobytes())

@@ -143,6 +143,54 @@ def test_f16_tile_scalar_store_path_is_exact(oracle, workdir, monkeypatch, tile,
     assert np.array_equal(out, _as_half(ref))
 
 
+@pytest.mark.parametrize("tile", [(192, 256), (128, 128), (64, 64)], ids=lambda t: "%dx%d" % t)
+@pytest.mark.parametrize("ksplit", [1, 3])
+def test_pooled_epilogue_with_negative_scales(oracle, workdir, monkeypatch, tile, ksplit):
+    """conv + 2x2 maxpool evaluates the epilogue ONCE per window, on the max (scale >= 0) or the min (scale < 0) of the
+    four accumulators: the epilogue is monotone, so this equals max over four evaluations exactly
+    (maxpool_layer.c:79-114 behind convolutional_layer.c:435-474)"""
+    bm, bn = tile
+    spec = [("conv", 64, 3, 0, "linear"), ("conv", bn + 40, 3, 1, "leaky"), ("max", 2, 2)]
+    cfg, wts, x = _small_int_conv_case(workdir, spec, 26, 2, 61000 + bm + bn + ksplit, neg_scale=True)
+    monkeypatch.setenv("Y2_CONV_TILE", "%dx%d" % tile)
+    monkeypatch.setenv("Y2_CONV_GRID", "3")
+    monkeypatch.setenv("Y2_CONV_KSPLIT", str(ksplit))
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    outs = []
+    for fuse in (True, False):
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        net.set_fusion(fuse)
+        outs.append(net.network_predict(x).copy())
+        assert ("+maxpool2" in net.layer_kernel(1)) == fuse
+        net.free()
+    on.close()
+    assert np.array_equal(outs[0], outs[1])                       # fused == conv then maxpool, bit for bit
+    assert np.abs(outs[0] - ref).max() <= np.abs(ref).max() * 2.0 ** -23
+    assert (ref < 0).any() and (ref > 0).any()
+
+
+def test_first_layer_pooled_epilogue_with_negative_scales(oracle, workdir):
+    """the 3-channel first-layer kernel (conv_first_kernel, pipelined batch-norm + leaky copy and generic copy)"""
+    for act in ("leaky", "linear"):
+        spec = [("conv", 32, 3, 1, act), ("max", 2, 2)]
+        cfg, wts, x = _small_int_conv_case(workdir, spec, 40, 3, 62000 + len(act), neg_scale=True)
+        on = oracle.OracleNet(cfg, wts)
+        ref = on.predict(x)
+        outs = []
+        for fuse in (True, False):
+            net = darknet.Network.parse_network_cfg(cfg)
+            net.load_weights(wts)
+            net.set_fusion(fuse)
+            outs.append(net.network_predict(x).copy())
+            assert net.layer_kernel(0).startswith("conv_first_mfma_f32") and ("+maxpool2" in net.layer_kernel(0)) == fuse
+            net.free()
+        on.close()
+        assert np.array_equal(outs[0], outs[1])
+        assert np.abs(outs[0] - ref).max() <= np.abs(ref).max() * 2.0 ** -23
+
+
 def test_kernel_name_pattern():
     for n in sorted(TESTED_F32 | TESTED_F16):
         assert re.fullmatch(r"conv_mfma_f(32|16)_\d+x\d+x\d+_k[13]", n)
