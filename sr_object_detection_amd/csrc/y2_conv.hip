@@ -99,10 +99,12 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // slices [ks*nk/ksplit, (ks+1)*nk/ksplit) of the K loop (split-K, for grids too small to fill 256 CUs).
     const int nk = KS * KS * (a.Cin / BK);
     int tap = 0, c0 = 0;      // position of the NEXT slice to load
+    int s_k = 0, s_n = 0;     // staging cursor: slices of its work item already fetched / slices that item has
     auto setup_tile = [&](int vtile) {
     const bool live = vtile < a.ntiles;
     const int tile = vtile / a.ksplit;
     const int kb = ((vtile - tile * a.ksplit) * nk) / a.ksplit;     // first slice of this work item
+    s_n = live ? (((vtile - tile * a.ksplit) + 1) * nk) / a.ksplit - kb : 0x40000000;    // past the end: never hop again
     c0 = (kb / (KS * KS)) * BK;
     tap = kb % (KS * KS);
     const int p0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         // 32-channel chunk touch the same (neighbouring) 128-byte pixel lines, so eight of the
         // nine A-slice reads hit L1/L2 instead of going back to the Infinity Cache / HBM.
         if (++tap == KS * KS) { tap = 0; c0 += BK; }     // the hop to the next tile is done by the K loop
+        ++s_k;
     };
     auto store_slice = [&](int buf) {
         float *As = smem + buf * BUF;
@@ -205,8 +208,20 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             if (BN % RP == 0 || sr + q * RP < BN) *(f32x4 *)&Bs[(sr + q * RP) * LS + sc * 4] = rb[q];
     };
 
+#ifdef Y2_NO_EARLYB
+    constexpr bool EB = false;
+#else
+    constexpr bool EB = PIPE && BK >= 32;
+#endif
     load_slice();
     store_slice(0);
+    if (EB) {
+        // EB keeps the staging side TWO slices ahead when it issues its loads (one register set: the slice is loaded
+        // under the last MFMA group of K-step k and written to LDS under the third group of step k+1, three groups of
+        // latency cover instead of two -- storing one group earlier stalled on the loads, profiles/r02_notes.md)
+        if (s_k == s_n) { setup_tile(tile_at(++lti)); s_k = 0; }
+        load_slice();
+    }
     __syncthreads();
 
     // EB ("early barrier", BK = 32 tiles): the slice fetched in this K-step is written to the other LDS buffer under the
@@ -215,11 +230,6 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // has just published -- a K-step boundary no longer exposes an LDS read latency with the matrix pipe idle.  Still
     // one barrier per K-step: every read of the current buffer is issued (and, by the barrier's lgkmcnt(0), returned)
     // before the barrier, so the buffer may be overwritten one step later without a second one.
-#ifdef Y2_NO_EARLYB
-    constexpr bool EB = false;
-#else
-    constexpr bool EB = PIPE && BK >= 32;
-#endif
     f32x4 af[2][TM], bf[2][TN];      // operand fragments, two register sets (EB: live across K-steps and tiles)
     if (EB) {
         const float *As0 = smem + (wm * (BM / WM) + li) * LS + lh * 4;
@@ -238,6 +248,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // plus the whole staging tail.  sched_barrier pins the phases against the compiler's scheduler.
     constexpr int NG = BK / 8;
     int cur = 0;
+#ifdef Y2_F32_STAMPS
+    // diagnostic: cycles per wave in [0] tile setup + accumulator clear, [1] K loop, [2] epilogue; [3] K-steps, [4] tiles
+    unsigned long long st[5] = {0, 0, 0, 0, 0}, st_bar = 0, st_prev = __builtin_amdgcn_s_memtime();
+#define F32_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[k] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define F32_STAMP(k) do { } while (0)
+#endif
     for (int cti = 0;; ++cti) {
     const int vt = tile_at(cti);
     if (vt >= a.ntiles) break;
@@ -252,11 +269,16 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // a wave in its K loop outranks co-resident waves that are in their (VALU / store) epilogue or tile setup
     __builtin_amdgcn_s_setprio(1);
+    F32_STAMP(0);
+#ifdef Y2_F32_STAMPS
+    st[3] += ke - kb; st[4] += 1;
+#endif
     for (int kt = kb; kt < ke; ++kt) {
-        if (kt == ke - 1) {
-            // the slice fetched during this (last) K-step is the first one of the block's next work
-            // item; switching here, outside the K-step body, keeps that body a single scheduling region
+        if (EB ? (s_k == s_n) : (kt == ke - 1)) {
+            // the slice fetched during this K-step is the first one of the block's next work item;
+            // switching here, outside the K-step body, keeps that body a single scheduling region
             setup_tile(tile_at(++lti));
+            s_k = 0;
         }
         const float *As = smem + cur * BUF + (wm * (BM / WM) + li) * LS + lh * 4;
         const float *Bs = smem + cur * BUF + BM * LS + (wn * (BN / WN) + li) * LS + lh * 4;
@@ -286,6 +308,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                 for (int j = 0; j < TN; ++j) bf[0][j] = *(const f32x4 *)&Bs[j * 32 * LS];
             }
             constexpr int SG = EB ? NG - 2 : NG - 1;      // group under which the fetched slice is written to LDS
+            constexpr int BG = EB ? NG - 2 : NG - 1;                  // group behind which the workgroup barrier sits
+            constexpr int LG = EB ? NG - 1 : 0;                       // group under which the next global loads are issued
 #pragma unroll
             for (int kg = 0; kg < NG; ++kg) {
                 const int c = kg & 1, n = c ^ 1;
@@ -303,8 +327,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bf[n][j] = *(const f32x4 *)&Bn[j * 32 * LS];
                 }
-                if (kg == 0) load_slice();
                 if (kg == SG) store_slice(cur ^ 1);
+                if (kg == LG) load_slice();               // (after the store when both fall into one group: same registers)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                 // fragment reads of the next group, then the staging work one piece per MFMA
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (kg + 1 < NG || EB) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-                if (kg == 0) {
+                if (kg == LG) {
 #pragma unroll
                     for (int q = 0; q < PA + PB; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -332,13 +356,24 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (EB && kg == SG) __syncthreads();
+#ifdef Y2_F32_STAMPS
+                if (EB && kg == BG) { const unsigned long long b0 = __builtin_amdgcn_s_memtime(); __syncthreads(); st_bar += __builtin_amdgcn_s_memtime() - b0; }
+#else
+                if (EB && kg == BG) {
+                    // raw barrier: only this wave's LDS traffic has to be complete (its slice stores and its reads of the
+                    // current buffer); __syncthreads() would also wait for the global loads that may already be in flight
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
             }
         }
         if (!EB || !PIPE) __syncthreads();
         cur ^= 1;
     }
     __builtin_amdgcn_s_setprio(0);
+    F32_STAMP(1);
 
     // epilogue: lane holds column (cout) li of each 32x32 tile and 16 rows (pixels)
     // (`bn` and `act` are uniform, but tested per output value they are real branches -- 1439 s_cbranch in the 192x256
@@ -442,7 +477,12 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         else if (a.bn && a.act == Y2H_ACT_LINEAR) epilogue_pass(std::integral_constant<int, 2>{}, std::false_type{});     // resnet's 1x1 expansions
         else epilogue_pass(std::integral_constant<int, 0>{}, std::false_type{});
     }
+    F32_STAMP(2);
     }   // tile loop
+#ifdef Y2_F32_STAMPS
+    if (lane == 0 && a.stamps)
+        for (int k = 0; k < 5; ++k) a.stamps[((size_t)blockIdx.x * (NT / 64) + wv) * 5 + k] = (k == 0) ? st_bar : st[k];      // [0]: barrier wait (setup dropped)
+#endif
 }
 
 // second pass of a split-K convolution: y[p][co] = epilogue(sum_s ws[s][p][co]), s ascending.  With the fused 2x2
@@ -1224,8 +1264,27 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         long grid = 256L * variant_bpc(*v);          // persistent: at most what is co-resident
         if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }   // tests: many tiles per workgroup on small shapes
         if (grid > a.ntiles) grid = a.ntiles;
+#ifdef Y2_F32_STAMPS
+        static unsigned long long *d_st = nullptr;
+        if (!d_st) Y2H_CHECK(hipMalloc((void **)&d_st, 1024 * 8 * 5 * sizeof(unsigned long long)));
+        Y2H_CHECK(hipMemsetAsync(d_st, 0, 1024 * 8 * 5 * sizeof(unsigned long long), S(s)));
+        a.stamps = d_st;
+#endif
         hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
         Y2H_LAUNCH_CHECK();
+#ifdef Y2_F32_STAMPS
+        if (getenv("Y2_F32_STAMPS")) {
+            static unsigned long long h[1024 * 8 * 5];
+            Y2H_CHECK(hipStreamSynchronize(S(s)));
+            Y2H_CHECK(hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost));
+            double tot[5] = {0, 0, 0, 0, 0};
+            const int waves = v->threads / 64;
+            for (long b = 0; b < grid; ++b) for (int w = 0; w < waves; ++w) for (int k = 0; k < 5; ++k) tot[k] += (double)h[(b * waves + w) * 5 + k];
+            const double tiles = tot[4] > 0 ? tot[4] : 1, steps = tot[3] > 0 ? tot[3] : 1;
+            fprintf(stderr, "f32 stamps %s %dx%d c%d n%d: per wave: K-step %.0f cycles of which %.0f at the barrier (%.1f steps per tile), epilogue %.0f per tile\n",
+                    v->name, d->h, d->w, d->c, d->n, tot[1] / steps, tot[0] / steps, steps / tiles, tot[2] / tiles);
+        }
+#endif
         if (ksplit > 1) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(y2h_grid((long)a.npix * a.Cout, 256)), dim3(256), 0, S(s), a);
             Y2H_LAUNCH_CHECK();

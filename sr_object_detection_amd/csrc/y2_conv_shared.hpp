@@ -31,6 +31,7 @@ struct ConvK {
     int ntiles;        // tiles_m * tiles_n * ksplit work items; workgroups walk them with stride gridDim.x
     int ksplit;        // >= 1: number of K ranges each output tile is cut into (split-K)
     float *ws;         // split-K partial sums [ksplit][npix][Cout]
+    unsigned long long *stamps;   // diagnostic builds (-DY2_F32_STAMPS): per-wave cycle counters
     // stride / out_h / out_w: fp32 matrix-core and direct kernels; size / pad / batch: direct kernel only
     int size, stride, pad, out_h, out_w, batch;
 };
