@@ -163,8 +163,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // i-th tile of this workgroup (a.ntiles = none): b, b+G, b+2G, ...  (Cutting the tile range into
     // one contiguous chunk per XCD, so that neighbouring pixel tiles share halo rows in one L2, was
     // measured slower on every layer: profiles/r01_notes.md.)
+    int wgid = blockIdx.x;
+    if (a.dbg & 64) {         // A/B (env Y2_CONV_XCD_REMAP): XCD-contiguous tile numbers (bijective for any grid)
+        const int nwg = gridDim.x, xcd = wgid & 7, q = nwg >> 3, r = nwg & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wgid >> 3);
+    }
     auto tile_at = [&](int i) -> int {
-        const long tl = (long)blockIdx.x + (long)i * gridDim.x;
+        const long tl = (long)wgid + (long)i * gridDim.x;
         return tl < a.ntiles ? (int)tl : a.ntiles;
     };
     int lti = 0;              // staging side: index of its tile in this workgroup's sequence
@@ -1261,6 +1266,7 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
             if (dev >= 0 && dev < 16) v->attr_set[dev] = true;
         }
         a.ntiles = (int)(tiles_m * a.tiles_n) * ksplit;
+        if (getenv("Y2_CONV_XCD_REMAP")) a.dbg |= 64;      // A/B switch; measured 0.2-0.5 % slower in the pipelined step (r02 notes)
         long grid = 256L * variant_bpc(*v);          // persistent: at most what is co-resident
         if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }   // tests: many tiles per workgroup on small shapes
         if (grid > a.ntiles) grid = a.ntiles;
