@@ -73,7 +73,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // 8-wave tiles (one workgroup per CU, LDS to spare): outputs leave as 16-byte stores through a wave-private LDS
     // transpose.  A lane of the accumulator layout owns ONE filter of 16 pixels -- sixteen 4-byte stores per 32x32 tile,
     // 96 per lane and tile, each with its own 64-bit address; transposed, a lane stores 4 consecutive filters of a pixel.
-    constexpr bool VST = (WM * WN == 8);
+    constexpr bool VST = true;
+    constexpr bool ES_OWN = (WM * WN == 8);   // 8-wave tiles: 18 KB of LDS of their own; 4-wave tiles (two workgroups per
+                                              // CU, no LDS to spare): the staging buffer the last K-step has just
+                                              // released, and a barrier behind the epilogue before it is written again
     constexpr int ES = 36;                // scratch row stride (floats): 32 filters + 16 B
 
     const int t = threadIdx.x;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                     // Stores go through the buffer descriptor of y with 32-bit offsets (rows past the end and filters
                     // past Cout get an out-of-range offset: the store is dropped, no exec masking, no 64-bit address math
                     // -- the scalar form spills 127 registers of hoisted 64-bit addresses in this tile shape).
-                    float *es = smem + 2 * BUF + wv * (16 * ES);
+                    float *es = (ES_OWN ? smem + 2 * BUF : smem + (cur ^ 1) * BUF) + wv * (16 * ES);
                     const int cb = n0 + wn * (BN / WN) + j * 32;          // first filter of this 32-wide tile
                     const int pb = p0 + wm * (BM / WM) + i * 32;          // first GEMM row of this tile
                     const int rrow = lane >> 3, rch = (lane & 7) * 4;     // read side: row 0..7 (+8), filters rch..rch+3
@@ -477,6 +480,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     };
     if (VST && a.vec_store && a.bn && a.act == Y2H_ACT_LEAKY) {        // (every conv of the target cfgs but the last)
         epilogue_pass(std::integral_constant<int, 1>{}, std::true_type{});
+        if (!ES_OWN) {            // the scratch lies in the buffer the next K-step stores its slice into
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     } else {
         if (a.bn && a.act == Y2H_ACT_LEAKY) epilogue_pass(std::integral_constant<int, 1>{}, std::false_type{});
         else if (a.bn && a.act == Y2H_ACT_LINEAR) epilogue_pass(std::integral_constant<int, 2>{}, std::false_type{});     // resnet's 1x1 expansions
