@@ -219,7 +219,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 #ifdef Y2_NO_EARLYB
     constexpr bool EB = false;
 #else
-    constexpr bool EB = PIPE && BK >= 32;
+    // (not the 64x64 tile: it is what batch-1 grids run, one short work item per workgroup, where the longer prologue of
+    // the two-slices-ahead staging costs 1-2 us per layer and buys nothing)
+    constexpr bool EB = PIPE && BK >= 32 && !(BM == 64 && BN == 64);
 #endif
     load_slice();
     store_slice(0);
@@ -229,8 +231,14 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         // latency cover instead of two -- storing one group earlier stalled on the loads, profiles/r02_notes.md)
         if (s_k == s_n) { setup_tile(tile_at(++lti)); s_k = 0; }
         load_slice();
+        // raw barrier: only the LDS stores of slice 0 have to be complete -- __syncthreads() would also wait for the
+        // second slice's loads just issued (one full memory latency per launch: 5 % of a batch-1 layer)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        __syncthreads();
     }
-    __syncthreads();
 
     // EB ("early barrier", BK = 32 tiles): the slice fetched in this K-step is written to the other LDS buffer under the
     // SECOND-TO-LAST MFMA group and the workgroup barrier follows that group; the last group then multiplies from
