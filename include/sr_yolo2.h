@@ -270,7 +270,7 @@ void y2_set_strict(network *net, int strict);
  * full-resolution activation is never stored); 0 turns that off, e.g. to inspect every layer. */
 void y2_set_fusion(network *net, int on);
 /* Measure instead of model: when the plan is (re)built, every convolution that runs on the fp32 matrix cores times
- * each instantiated tile shape (and a few K-splits) on its own buffers and keeps the fastest (y2h_conv_tune); the result
+ * each instantiated tile shape (and a few K-splits) inside whole forward passes and keeps the fastest (y2h_conv_candidates); the result
  * is remembered per layer shape for the life of the process.  Costs about a second per network at plan time.  A tile
  * shape never changes a result bit; a different K-split changes the last bits of that layer (fixed-order partial sums).
  * Off by default; env Y2_AUTOTUNE=1 turns it on for every network.  Ignored in strict mode. */

@@ -132,21 +132,16 @@ typedef struct y2h_conv {
     int           y_f16;         /* 1: y is stored as half (ldy counts halves)         */
     const float  *alpha;         /* device [n]  scale/(sqrt(var)+1e-6)  (1 without BN)  */
     const float  *beta;          /* device [n]  bias - mean*alpha                       */
-    /* tile choice of the matrix-core kernel: 0 = the host's cost model decides; set by y2h_conv_tune */
+    /* tile choice of the matrix-core kernel: 0 = the host's cost model decides (see y2h_conv_candidates) */
     int           tile_bm, tile_bn;   /* GEMM tile (output pixels x filters), one of the instantiated shapes */
     int           ksplit;             /* K ranges per output tile (1 = no split-K) */
 } y2h_conv;
 
-/* Measure instead of model: time every instantiated tile shape (and a few K-splits) of the matrix-core kernel on THIS
- * descriptor's buffers (`reps` launches each on stream s, after one warm-up) and store the fastest in
- * d->tile_bm / tile_bn / ksplit.  The output buffer is overwritten with results computed from whatever x holds.
- * Every tile shape accumulates each output in the same K order, so the choice of tile never changes a result bit;
- * a K-split does (partial sums are added in a fixed order).  Returns the number of candidates timed (0: the descriptor
- * does not run on the fp32 matrix-core kernel), < 0 on error. */
-int y2h_conv_tune(y2h_conv *d, int reps, y2h_stream s);
-/* the (tile_bm, tile_bn, ksplit) combinations y2h_conv_tune would time, for callers that measure in their own context
- * (the engine times them inside whole forward passes, where the caches hold what they hold in production); entry 0 is
- * the cost model's choice.  Returns the count (0: not an fp32 matrix-core convolution). */
+/* Measure instead of model: the (tile_bm, tile_bn, ksplit) combinations worth timing for this descriptor, for callers
+ * that measure in their own context (the engine, y2_set_autotune, times them inside whole forward passes, where the
+ * caches hold what they hold in production); entry 0 is the cost model's choice.  Every tile shape accumulates each
+ * output in the same K order, so the choice of tile never changes a result bit; a K-split does (partial sums are added
+ * in a fixed order).  Returns the count (0: not an fp32 matrix-core convolution). */
 int y2h_conv_candidates(const y2h_conv *d, int *bm, int *bn, int *ks, int max);
 
 /* which kernel y2h_conv_forward would pick: 1 = MFMA implicit GEMM, 0 = direct VALU */

@@ -970,7 +970,7 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
     const long npix = (long)d->batch * d->out_h * d->out_w;
     const int nk = d->size * d->size * (d->c / bk);
     const int CUS = 256;
-    int force_bm = d->tile_bm, force_bn = d->tile_bn, force_split = d->ksplit;      // a tuned descriptor (y2h_conv_tune)
+    int force_bm = d->tile_bm, force_bn = d->tile_bn, force_split = d->ksplit;      // a tuned descriptor (y2_set_autotune)
     if (const char *f = getenv("Y2_CONV_TILE")) sscanf(f, "%dx%d", &force_bm, &force_bn);
     if (const char *f = getenv("Y2_CONV_KSPLIT")) force_split = atoi(f);
     Variant *best = nullptr;
@@ -1022,7 +1022,9 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
 
 // ---------------------------------------------------------------------------
 // Tile autotuning: the cost model above ranks tile shapes from grid arithmetic; on small grids (batch 1..8) its
-// error is 10-40 % of a layer (profiles/r02_notes.md), so a plan may instead MEASURE each shape once.
+// error is 10-40 % of a layer (profiles/r02_notes.md), so a plan may instead MEASURE each shape once.  The engine times
+// the candidates inside whole forward passes (y2_engine.c autotune_layers): timed in isolation, back to back, a layer
+// finds its own weights in the Infinity Cache and small tiles look better than they are in the real sequence.
 // ---------------------------------------------------------------------------
 // the (tile, K-split) combinations worth measuring for a descriptor; entry 0 is the cost model's own choice
 extern "C" int y2h_conv_candidates(const y2h_conv *d, int *bm, int *bn, int *ks, int max)
@@ -1053,60 +1055,6 @@ extern "C" int y2h_conv_candidates(const y2h_conv *d, int *bm, int *bn, int *ks,
         }
     }
     return n;
-}
-
-extern "C" int y2h_conv_tune(y2h_conv *d, int reps, y2h_stream s)
-{
-    if (!d || reps < 1) return Y2H_EINVAL;
-    if (d->x_f16 || d->x_halo != 0 || !mfma_ok(d)) return 0;
-    const int bk = (d->c % 32 == 0) ? 32 : 16;
-    const int nk = d->size * d->size * (d->c / bk);
-    y2h_conv t = *d;
-    t.tile_bm = t.tile_bn = t.ksplit = 0;
-    int model_split = 1;
-    Variant *mv = pick_variant(&t, &model_split);
-    if (!mv) return 0;
-    hipEvent_t e0, e1;
-    Y2H_CHECK(hipEventCreate(&e0));
-    Y2H_CHECK(hipEventCreate(&e1));
-    float best_ms = 1e30f;
-    int best_bm = mv->bm, best_bn = mv->bn, best_split = model_split, tried = 0, rc = Y2H_OK;
-    for (Variant &v : g_variants) {
-        if (v.bk != bk || v.ks != d->size) continue;
-        // K-splits worth a try: none, the model's, and its neighbours
-        int splits[5] = {1, model_split, model_split * 2, model_split / 2, 0}, ns = 4;
-        {   // what the model would do with THIS tile
-            y2h_conv q = t; q.tile_bm = v.bm; q.tile_bn = v.bn;
-            int ks = 1;
-            if (pick_variant(&q, &ks)) splits[ns++] = ks;
-        }
-        for (int a = 0; a < ns && rc == Y2H_OK; ++a) {
-            const int ks = splits[a];
-            bool dup = ks < 1 || ks > nk;
-            for (int b = 0; b < a; ++b) dup = dup || splits[b] == ks;
-            if (dup) continue;
-            if (ks > 1 && (!d->ws || (size_t)ks * d->batch * d->out_h * d->out_w * d->n * sizeof(float) > d->ws_bytes)) continue;
-            y2h_conv q = t;
-            q.tile_bm = v.bm; q.tile_bn = v.bn; q.ksplit = ks;
-            if ((rc = y2h_conv_forward(&q, 0, s)) != Y2H_OK) break;            // warm-up (and LDS attribute)
-            if (hipEventRecord(e0, S(s)) != hipSuccess) { rc = Y2H_EHIP; break; }
-            for (int r = 0; r < reps && rc == Y2H_OK; ++r) rc = y2h_conv_forward(&q, 0, s);
-            if (rc != Y2H_OK) break;
-            float ms = 0.f;
-            if (hipEventRecord(e1, S(s)) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = Y2H_EHIP; break; }
-            ++tried;
-            // a different tile must win by 2 % (timer noise), otherwise the model's choice stays
-            const bool is_model = (v.bm == mv->bm && v.bn == mv->bn && ks == model_split);
-            if (ms * (is_model ? 0.98f : 1.0f) < best_ms) { best_ms = ms * (is_model ? 0.98f : 1.0f); best_bm = v.bm; best_bn = v.bn; best_split = ks; }
-        }
-        if (rc != Y2H_OK) break;
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (rc != Y2H_OK) return rc;
-    d->tile_bm = best_bm; d->tile_bn = best_bn; d->ksplit = best_split;
-    return tried;
 }
 
 extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)
