@@ -46,6 +46,9 @@ WORKLOADS = {
     # configs[1]
     "yolo416_b8": dict(net="yolo", size=416, batch=8),
     "tiny416_b1": dict(net="tiny-yolo-voc", size=416, batch=1),
+    # the robot's own call pattern (one frame per test_detector_img call) on the large nets
+    "yolo608_b1": dict(net="yolo", size=608, batch=1),
+    "yolo416_b1": dict(net="yolo", size=416, batch=1),
     # configs[3] per-GPU share (64 frames over 8 GPUs), synthetic 9418-node tree (cfg/9k.tree is corrupt)
     "yolo9000_544_b8": dict(net="yolo9000", size=544, batch=8),
     # configs[4]: darknet19_448 classifier, fp16 storage / fp32 accumulate on the fp16 matrix cores; and in fp32

@@ -204,7 +204,8 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     c->batch_normalize = l->batch_normalize;
     c->activation = act_for_kernel(l->activation);
     c->x = x;
-    c->x_halo = (i == 0 && e->in_halo) ? e->in_halo_px : 0;   /* in_halo 2: half [b][h+2][w+2][4] for the fp16 first-layer kernel */
+    c->x_halo = (i == 0 && e->in_halo && e->in_halo != 3) ? e->in_halo_px : 0;   /* in_halo 2: half [b][h+2][w+2][4] for the fp16 first-layer kernel;
+                                                                                    3: that kernel reads the fp32 NCHW input itself */
     if (i > 0 && ld_of(&net->layers[i - 1])->d_halo) c->x_halo = ld_of(&net->layers[i - 1])->halo_px;
     if (l->xnor) c->x_halo = 0;
     c->fuse_maxpool2 = d->fused_pool;
@@ -213,6 +214,7 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
     c->y = d->out;
     c->y_f16 = d->out_half;
     c->x_f16 = (i > 0) ? ld_of(&net->layers[i - 1])->out_half : (e->in_halo == 2);
+    c->x_nchw = (i == 0 && e->in_halo == 3);
     c->tile_bm = d->tile_bm; c->tile_bn = d->tile_bn; c->ksplit = d->ksplit;
     if (e->arena) {
         c->w_packed = (const float *)(e->arena + d->off_w_packed);
@@ -233,7 +235,7 @@ static void conv_desc(const network *net, int i, y2h_conv *c, const float *x, in
 static void input_view(const network *net, int i, const float **x, int *ldx)
 {
     const y2_engine *e = y2_engine_of(net);
-    if (i == 0) { *x = e->d_in_nhwc; *ldx = (e->in_halo == 2) ? 4 : net->c; }
+    if (i == 0) { *x = (e->in_halo == 3) ? e->cur_input : e->d_in_nhwc; *ldx = (e->in_halo == 2) ? 4 : net->c; }
     else {
         const y2_ldev *p = ld_of(&net->layers[i - 1]);
         *x = p->out; *ldx = p->out_ld;
@@ -765,11 +767,18 @@ int y2_engine_build(network *net)
         }
         /* fp16 mode: the first layer reads a half [b][h+2][w+2][4] copy of the input on the fp16 matrix cores */
         if (e->half && ld_of(l0)->out_half && net->c <= 4 && y2h_conv_first_layer_f16_ok(&c0)) e->in_halo = 2;
+        /* ... or, where the shape allows, reads the fp32 planes of the network input directly: no transform kernel */
+        if (e->in_halo == 2) {
+            c0.fuse_maxpool2 = ld_of(l0)->fused_pool;
+            c0.x = (const float *)(uintptr_t)256;
+            if (y2h_conv_first_layer_nchw_ok(&c0)) e->in_halo = 3;
+        }
     }
     HIPCALL(y2h_malloc((void **)&e->d_in_nchw, e->in_floats * sizeof(float)));
     {
         size_t nhwc = e->in_halo ? (size_t)net->batch * (net->h + 2 * e->in_halo_px) * (net->w + 2 * e->in_halo_px) * net->c : e->in_floats;
         if (e->in_halo == 2) nhwc = (size_t)net->batch * (net->h + 2) * (net->w + 2) * 2;   /* 4 halves = 2 floats per pixel */
+        if (e->in_halo == 3) nhwc = 64;                                                      /* not used */
         HIPCALL(y2h_malloc((void **)&e->d_in_nhwc, nhwc * sizeof(float)));
         HIPCALL(y2h_memset(e->d_in_nhwc, 0, nhwc * sizeof(float), e->stream));     /* the halo stays zero */
     }
@@ -1001,7 +1010,11 @@ static int enqueue_forward(network *net, const float *d_input_nchw)
 {
     y2_engine *e = y2_engine_of(net);
     int i, k;
-    if (e->in_halo == 2)
+    e->cur_input = d_input_nchw;
+    if (e->in_halo == 3 && ((uintptr_t)d_input_nchw % 16) == 0)
+        ;                                                       /* the first layer reads d_input_nchw */
+    else if (e->in_halo == 3) { y2_fail("the fp16 first layer needs a 16-byte aligned network input"); return -1; }
+    else if (e->in_halo == 2)
         HIPCALL(y2h_nchw_to_nhwc4_halo_f16(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, e->stream));
     else if (e->in_halo)
         HIPCALL(y2h_nchw_to_nhwc_halo(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, net->c, e->in_halo_px, e->stream));

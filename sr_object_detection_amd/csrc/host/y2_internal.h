@@ -53,7 +53,9 @@ typedef struct y2_engine {
     int fusion, built_fusion;  /* conv+maxpool fusion enabled / state of the current plan */
     int half, built_half;      /* fp16 storage requested (y2_set_half) / state of the current plan */
     int autotune, built_autotune; /* measure the conv tile shapes at plan time (y2_set_autotune) */
-    int in_halo;               /* the NHWC copy of the input carries a zero border (2: the half NHWC4 form) */
+    int in_halo;               /* the NHWC copy of the input carries a zero border (2: the half NHWC4 form; 3: no copy at all,
+                                  the fp16 first layer reads the fp32 NCHW input) */
+    const float *cur_input;    /* the NCHW input of the forward pass being enqueued (in_halo 3) */
     int in_halo_px;            /* its width in pixels: 1 for the 3x3 first-layer kernels, the padding for the stem kernel */
     /* hipGraph replay of the forward launch sequence (y2_set_graph): recorded for one input pointer, dropped with the plan */
     y2h_event ev_out;          /* recorded behind the output copy of y2_output_enqueue */

@@ -1116,14 +1116,24 @@ extern "C" int y2h_conv_first_layer_f16_ok(const y2h_conv *d)
     return y2_f16_first_ok(&t) ? 1 : 0;
 }
 
+extern "C" int y2h_conv_first_layer_nchw_ok(const y2h_conv *d)
+{
+    y2h_conv t = *d;
+    t.x_halo = 0; t.x_f16 = 0; t.x_nchw = 1; t.y_f16 = 1;
+    if (!t.x) t.x = (const float *)(uintptr_t)256;
+    return y2_f16_first_nchw_ok(&t) ? 1 : 0;
+}
+
 extern "C" int y2h_conv_uses_mfma(const y2h_conv *d)
 {
+    if (d->x_nchw) return y2_f16_first_nchw_ok(d) ? 1 : 0;
     if (d->x_f16) return (y2_f16_first_ok(d) || y2_f16_conv_ok(d)) ? 1 : 0;
     return first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d)) || (d->c <= 4 && stem_ok(d)) ? 1 : 0;
 }
 
 extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
 {
+    if (d->x_nchw) return (!strict && y2_f16_first_nchw_ok(d)) ? (d->n <= 32 ? "conv_first_mfma_f16_nchw_c3_n32" : "conv_first_mfma_f16_nchw_c3_n64") : nullptr;
     if (!strict && first_ok(d)) return d->n <= 32 ? "conv_first_mfma_f32_c3_n32" : "conv_first_mfma_f32_c3_n64";
     if (d->x_f16) {
         if (!strict && y2_f16_first_ok(d)) return d->n <= 32 ? "conv_first_mfma_f16_c3_n32" : "conv_first_mfma_f16_c3_n64";
@@ -1156,6 +1166,12 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     a.size = d->size; a.stride = d->stride; a.pad = d->pad; a.out_h = d->out_h; a.out_w = d->out_w; a.batch = d->batch;
     a.y_f16 = d->y_f16;
 
+    if (d->x_nchw) {
+        // the network input itself (fp32 planes): only the fused fp16 first-layer kernel reads that layout
+        if (strict || !y2_f16_first_nchw_ok(d)) return Y2H_EINVAL;
+        a.pool = d->fuse_maxpool2 ? 1 : 0;
+        return y2_f16_first_nchw_launch(d, a, s);
+    }
     if (d->fuse_maxpool2) {
         // only the matrix-core kernels pool in their epilogue, and 2x2/2 windows need even dims
         if (strict || (d->h & 1) || (d->w & 1) ||

@@ -1313,6 +1313,258 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(ConvK a)
     else run(std::false_type{});
 }
 
+// ---------------------------------------------------------------------------
+// The same layer straight from the network input as the API hands it over: fp32 NCHW planes (x_nchw = 1).
+//
+// conv_first_f16_kernel needs the half NHWC4 haloed copy, i.e. one more kernel that reads 12 and writes 8 bytes per
+// pixel, and then reads every pixel through L1 nine times as 8-byte pieces.  Here a workgroup owns BANDS of eight image
+// rows: it reads the band's three fp32 planes (+ one row above and below) with 16-byte loads, coalesced along x,
+// converts to half and writes [row][x][4 halves] with a zero halo into LDS -- the layout the MFMA operand wants --
+// and its four waves then walk the band's 32-pixel tiles with the operand coming from LDS (ds_read_b64 per tap pair;
+// the row stride is padded to 16 mod 32 pixels so the two image rows of a pooled tile fall into different bank halves).
+// HBM sees the input once (9/8 with the band halo, which L2 absorbs) and the half output once.  Same K layout, filter
+// fragments, epilogue and stores as conv_first_f16_kernel.  Workgroups are persistent (setup once, bands with stride
+// gridDim.x); LDS per workgroup = 10 rows x 8 B x stride + the epilogue scratch, so 3-4 workgroups share a CU and one's
+// band load overlaps the others' matrix work.
+// ---------------------------------------------------------------------------
+__host__ __device__ static inline int first_nchw_stride(int W)
+{
+    const int s = W + 3;                                  // slot 0 unused (keeps pixel 0 16-byte aligned), 1 = left halo, W + 2 = right halo
+    return s + ((16 - s % 32) + 32) % 32;                 // == 16 (mod 32) pixels, i.e. 32 (mod 64) LDS banks
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_first_nchw_f16_kernel(ConvK a)
+{
+    constexpr int R = 8;                                  // image rows per band (even: pooling windows never straddle bands)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
+    const int t = threadIdx.x, lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int W = a.W, H = a.H;
+    const int stride = first_nchw_stride(W);
+    unsigned char *first_es = fb_smem + (size_t)(R + 2) * stride * 8;
+
+    unsigned delta[3][2];
+    bool live[3][2];
+    f16x8 bw[NT][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tap = 4 * s + 2 * lh + u;
+            live[s][u] = tap < 9;
+            const int tt = live[s][u] ? tap : 0;
+            const int kh = tt / 3, kw = tt - kh * 3;
+            delta[s][u] = (unsigned)((kh * stride + kw) * 8);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = j * 32 + li;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    float w = 0.f;
+                    if (live[s][u] && ci < 3 && co < a.Cout) w = a.w[(size_t)co * 27 + tap * 3 + ci];
+                    bw[j][s][u * 4 + ci] = (_Float16)w;
+                }
+            }
+        }
+    float alpha[NT], beta[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = j * 32 + li;
+        alpha[j] = 0.f; beta[j] = 0.f;
+        if (co < a.Cout) {
+            double al = 1.0, be = a.bias[co];
+            if (a.bn) { al = (double)a.scale[co] * a.rinv[co]; be = (double)a.bias[co] - (double)a.mean[co] * al; }
+            alpha[j] = (float)al; beta[j] = (float)be;
+        }
+    }
+
+    const int bands_per_img = (H + R - 1) / R;
+    const int nbands = a.batch * bands_per_img;
+    const int Wu = a.pool ? W >> 1 : W, Hu = a.pool ? H >> 1 : H;
+    const int tpr = a.pool ? (Wu + 7) >> 3 : (W + 31) >> 5;           // tiles per row of units
+    const size_t plane = (size_t)H * W;
+    const int wq = W >> 2;
+    _Float16 *yh = (_Float16 *)a.y;
+
+    auto pack2 = [](float lo, float hi) -> unsigned {
+        return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hi) << 16);
+    };
+
+    auto run = [&](auto FASTC) {
+        constexpr bool FAST = decltype(FASTC)::value;
+        const int ACT_ = FAST ? (int)Y2H_ACT_LEAKY : a.act;
+        for (int band = blockIdx.x; band < nbands; band += gridDim.x) {
+            const int n = band / bands_per_img, y0 = (band - n * bands_per_img) * R;
+            const int rows = (H - y0 < R) ? H - y0 : R;
+            __syncthreads();                                          // the previous band's operand reads are done
+            // ---- stage: rows y0-1 .. y0+R of the three planes -> half [r][slot][4]; rows outside the image are zeros ----
+            const float *img = a.x + (size_t)n * 3 * plane;
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const int r = wv + 4 * rr;
+                if (r < R + 2) {
+                    const int y = y0 - 1 + r;
+                    const bool yin = y >= 0 && y < H;
+                    unsigned char *row = fb_smem + (size_t)r * stride * 8;
+                    for (int g0 = 0; g0 < wq; g0 += 128) {
+                        f32x4 c[2][3];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int g = g0 + 64 * h + lane;
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) {
+                                c[h][ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                if (yin && g < wq) c[h][ch] = *(const f32x4 *)(img + ch * plane + (size_t)y * W + 4 * g);
+                            }
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int g = g0 + 64 * h + lane;
+                            if (g < wq) {
+                                u32x4 v0, v1;
+                                v0[0] = pack2(c[h][0][0], c[h][1][0]); v0[1] = pack2(c[h][2][0], 0.f);
+                                v0[2] = pack2(c[h][0][1], c[h][1][1]); v0[3] = pack2(c[h][2][1], 0.f);
+                                v1[0] = pack2(c[h][0][2], c[h][1][2]); v1[1] = pack2(c[h][2][2], 0.f);
+                                v1[2] = pack2(c[h][0][3], c[h][1][3]); v1[3] = pack2(c[h][2][3], 0.f);
+                                *(u32x4 *)(row + (size_t)(2 + 4 * g) * 8) = v0;
+                                *(u32x4 *)(row + (size_t)(2 + 4 * g) * 8 + 16) = v1;
+                            }
+                        }
+                    }
+                    if (lane < 2) *(u32x2 *)(row + (size_t)(lane ? W + 2 : 1) * 8) = u32x2{0u, 0u};
+                }
+            }
+            __syncthreads();
+
+            // ---- tiles of the band: wave wv takes tiles wv, wv + 4, ... (row-major over the band's unit rows) ----
+            const int urows = a.pool ? rows >> 1 : rows;
+            const int ntile = urows * tpr;
+            auto load_tile = [&](int trow, int tcol, u32x2 (&av)[3][2]) {
+                const int ux = a.pool ? tcol * 8 + (li >> 2) : tcol * 32 + li;
+                const int px = a.pool ? 2 * ux + (li & 1) : ux, pyr = a.pool ? 2 * trow + ((li >> 1) & 1) : trow;
+                const unsigned base = ((unsigned)(pyr * stride) + (unsigned)(ux < Wu ? px : 0) + 1u) * 8u;
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const u32x2 v = *(const u32x2 *)(fb_smem + base + delta[s][u]);
+                        av[s][u] = live[s][u] ? v : u32x2{0u, 0u};         // taps 9..11 do not exist
+                    }
+            };
+            auto compute_tile = [&](int trow, int tcol, const u32x2 (&av)[3][2]) {
+                f32x16 acc[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    u32x4 q;
+                    q[0] = av[s][0][0]; q[1] = av[s][0][1]; q[2] = av[s][1][0]; q[3] = av[s][1][1];
+                    const f16x8 af = __builtin_bit_cast(f16x8, q);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bw[j][s], acc[j], 0, 0, 0);
+                }
+                // first unit (pooled pixel / pixel) of the tile in the output, and how many of its units exist
+                const int u0 = a.pool ? tcol * 8 : tcol * 32;
+                const size_t obase = ((size_t)n * Hu + (size_t)((a.pool ? y0 >> 1 : y0) + trow)) * Wu + u0;
+                const int nu = Wu - u0;                                    // units of this tile inside the row (>= 1)
+                if (FAST || (a.pool && a.vec_store)) {
+                    unsigned char *es = first_es + wv * 8 * 144;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], ACT_);
+#pragma unroll
+                            for (int tt = 1; tt < 4; ++tt) m = __builtin_fmaxf(m, epilogue_fast(acc[j][4 * g + tt], alpha[j], beta[j], ACT_));
+                            *(_Float16 *)(es + (2 * g + lh) * 144 + (32 * j + li) * 2) = (_Float16)m;
+                        }
+                    const u32x4 v = *(const u32x4 *)(es + (lane >> 3) * 144 + (lane & 7) * 16);
+                    if ((lane & 7) * 8 < a.Cout && (lane >> 3) < nu) *(u32x4 *)&yh[(obase + (lane >> 3)) * a.ldy + (lane & 7) * 8] = v;
+                    return;
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int co = j * 32 + li;
+                    if (a.pool) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float m = epilogue_fast(acc[j][4 * g], alpha[j], beta[j], ACT_);
+#pragma unroll
+                            for (int tt = 1; tt < 4; ++tt) {
+                                const float v = epilogue_fast(acc[j][4 * g + tt], alpha[j], beta[j], ACT_);
+                                m = (v > m) ? v : m;
+                            }
+                            const int ui = lh + 2 * g;
+                            if (co < a.Cout && ui < nu) yh[(obase + ui) * a.ldy + co] = (_Float16)m;
+                        }
+                        continue;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ui = 4 * lh + (r & 3) + 8 * (r >> 2);
+                        if (co < a.Cout && ui < nu) yh[(obase + ui) * a.ldy + co] = (_Float16)epilogue_fast(acc[j][r], alpha[j], beta[j], ACT_);
+                    }
+                }
+            };
+            u32x2 a0[3][2], a1[3][2];
+            int lr = wv / tpr, lc = wv - lr * tpr;                        // cursor of the next tile to load
+            auto step4 = [&](int &r_, int &c_) { c_ += 4; while (c_ >= tpr) { c_ -= tpr; ++r_; } };
+            int ti = wv;
+            if (ti < ntile) load_tile(lr, lc, a0);
+            for (; ti < ntile; ti += 8) {
+                const int r0 = lr, c0 = lc;
+                step4(lr, lc);
+                if (ti + 4 < ntile) load_tile(lr, lc, a1);
+                compute_tile(r0, c0, a0);
+                const int r1 = lr, c1 = lc;
+                step4(lr, lc);
+                if (ti + 8 < ntile) load_tile(lr, lc, a0);
+                if (ti + 4 < ntile) compute_tile(r1, c1, a1);
+            }
+        }
+    };
+    if (a.act == Y2H_ACT_LEAKY && a.pool && a.vec_store) run(std::true_type{});
+    else run(std::false_type{});
+}
+
+static size_t first_nchw_lds(int W) { return (size_t)10 * first_nchw_stride(W) * 8 + 4 * 8 * 144; }
+
+// x is the fp32 NCHW network input (x_nchw = 1, x_f16 = 0), the output is half; weights are the fp32 packed [n][27]
+bool y2_f16_first_nchw_ok(const y2h_conv *d)
+{
+    if (!d->x_nchw || d->x_f16 || !d->y_f16 || d->x_halo) return false;
+    if (d->c != 3 || d->size != 3 || d->stride != 1 || d->pad != 1 || d->n > 64) return false;
+    if (d->out_h != d->h || d->out_w != d->w || (d->w & 3)) return false;
+    if (d->fuse_maxpool2 && ((d->h | d->w) & 1)) return false;
+    if (first_nchw_lds(d->w) > 64 * 1024 || getenv("Y2_NO_FIRST_NCHW")) return false;
+    return d->w_packed != nullptr && ((uintptr_t)d->x % 16) == 0;
+}
+
+int y2_f16_first_nchw_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
+{
+    a.w = d->w_packed;
+    a.npix = d->batch * d->h * d->w;
+    a.vec_store = d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !getenv("Y2_C32_SCALAR");
+    const size_t lds = first_nchw_lds(d->w);
+    const long nbands = (long)d->batch * ((d->h + 7) / 8);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    long blocks = 256L * per_cu;
+    if (blocks > nbands) blocks = nbands;
+    void (*fn)(ConvK) = d->n <= 32 ? conv_first_nchw_f16_kernel<1> : conv_first_nchw_f16_kernel<2>;
+    static bool attr[2];
+    if (!attr[d->n > 32]) {
+        if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return Y2H_EHIP;
+        attr[d->n > 32] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), lds, S(s), a);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
 // x is the half NHWC4 haloed input (x_f16 = 1, x_halo = 1, ldx = 4), weights are the fp32 packed [n][27]
 bool y2_f16_first_ok(const y2h_conv *d)
 {

@@ -117,3 +117,5 @@ const char *y2_f16_conv_variant(const y2h_conv *d);
 int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s);
 bool y2_f16_first_ok(const y2h_conv *d);
 int y2_f16_first_launch(const y2h_conv *d, ConvK &a, y2h_stream s);
+bool y2_f16_first_nchw_ok(const y2h_conv *d);
+int y2_f16_first_nchw_launch(const y2h_conv *d, ConvK &a, y2h_stream s);

@@ -191,6 +191,40 @@ def test_first_layer_pooled_epilogue_with_negative_scales(oracle, workdir):
         assert np.abs(outs[0] - ref).max() <= np.abs(ref).max() * 2.0 ** -23
 
 
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("filters,size", [(32, 40), (64, 36), (24, 20), (20, 24), (32, 132)])
+def test_f16_first_layer_reads_the_nchw_input(oracle, workdir, monkeypatch, filters, size, pool):
+    """fp16 mode, first layer straight from the fp32 NCHW network input (conv_first_nchw_f16_kernel: bands of eight rows
+    staged in LDS; 36 and 20 end in a partial band, 132 has two 64-lane passes per staged row and partial tiles at the
+    row end, 64 filters = two MFMA column tiles): exact against the oracle on integer data, and bit-identical to the
+    two-kernel form (input transform + conv_first_f16_kernel) with batch-norm + leaky"""
+    for bn, act in ((0, "linear"), (1, "leaky")):
+        spec = [("conv", filters, 3, bn, act)] + ([("max", 2, 2)] if pool else [])
+        cfg, wts, x = _small_int_conv_case(workdir, spec, size, 3, 64000 + filters + size + pool + bn, neg_scale=bool(bn))
+        outs = []
+        for direct in (True, False):
+            if direct:
+                monkeypatch.delenv("Y2_NO_FIRST_NCHW", raising=False)
+            else:
+                monkeypatch.setenv("Y2_NO_FIRST_NCHW", "1")
+            net = darknet.Network.parse_network_cfg(cfg)
+            net.load_weights(wts)
+            net.set_half(True)
+            outs.append(net.network_predict(x).copy())
+            want = "conv_first_mfma_f16_nchw_c3_n%d" % (32 if filters <= 32 else 64) if direct else "conv_first_mfma_f16_c3_n%d" % (32 if filters <= 32 else 64)
+            assert net.layer_kernel(0) == want + ("+maxpool2" if pool else ""), net.layer_kernel(0)
+            net.free()
+        assert np.array_equal(outs[0], outs[1])
+        on = oracle.OracleNet(cfg, wts)
+        ref = on.predict(x)
+        on.close()
+        if not bn:
+            assert np.abs(ref).max() < 60000
+            assert np.array_equal(outs[0], _as_half(ref))
+        else:
+            assert np.abs(outs[0] - ref).max() <= np.abs(ref).max() * 2.0 ** -10
+
+
 def test_kernel_name_pattern():
     for n in sorted(TESTED_F32 | TESTED_F16):
         assert re.fullmatch(r"conv_mfma_f(32|16)_\d+x\d+x\d+_k[13]", n)
