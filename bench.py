@@ -79,6 +79,10 @@ def parse_args():
                          "host_input, never as value); only: time just that; off: skip it")
     ap.add_argument("--bcast", default=os.environ.get("Y2_BENCH_BCAST", "torch"), choices=["torch", "c-abi"],
                     help="transport of the one weight broadcast at N>1")
+    ap.add_argument("--detect-overlap", type=int, default=-1,
+                    help="1: decode/NMS of step i on their own stream beside the forward of step i+1 (y2_set_detect_overlap); "
+                         "-1: only for wide heads (>= 1000 classes: yolo9000 +5-7 %%; neutral to -1 %% on the 80-class heads, whose "
+                         "decode kernels just queue between the persistent conv grids)")
     ap.add_argument("--autotune", type=int, default=0,
                     help="1: the plan measures the conv tile shapes once instead of modelling them (y2_set_autotune)")
     ap.add_argument("--dump-dets", default=None, help="write each rank's last-batch detections to PATH.rank<r>.npz")
@@ -356,6 +360,9 @@ def main():
     net = darknet.Network.parse_network_cfg(cfg, gpu=device_index)
     net.set_half(half)
     net.set_autotune(bool(args.autotune))
+    detect_overlap = bool(args.detect_overlap) if args.detect_overlap >= 0 else (
+        darknet.LAYER_TYPES[net.last.type] == "REGION" and net.last.classes >= 1000)
+    net.set_detect_overlap(detect_overlap)
     wts = os.path.join(tmp, "net.weights")
     if rank == 0:
         synth.write_weights(wts, layers, args.seed)
@@ -600,6 +607,7 @@ def main():
                            "inputs in pinned host memory (PCIe-inclusive)" if args.host_input == "only" else "inputs resident in HBM"),
                        "global_batch": batch * world, "parallelism": "frame-sharded x%d (one weight broadcast)" % world,
                        "tile_choice": "measured at plan time (y2_set_autotune)" if args.autotune else "host cost model",
+                       "detect_overlap": detect_overlap,
                        "weight_broadcast": bcast_how, "weight_broadcast_ms": bcast_ms,
                        "gflop_per_image": round(zoo.conv_flops(layers) / 1e9, 3),
                        "conv_ms_per_step": round(conv_ms, 3),

@@ -275,6 +275,12 @@ void y2_set_fusion(network *net, int on);
  * shape never changes a result bit; a different K-split changes the last bits of that layer (fixed-order partial sums).
  * Off by default; env Y2_AUTOTUNE=1 turns it on for every network.  Ignored in strict mode. */
 void y2_set_autotune(network *net, int on);
+/* Throughput mode for callers that pipeline batches with y2_detect_enqueue / y2_detect_fetch: decode, NMS and
+ * compaction of batch i run on a stream of their own, so their small grids (one workgroup per image and class group)
+ * share the GPU with the forward pass of batch i+1 instead of idling it; the forward pass waits for them only before
+ * its region layer overwrites the tensor they read.  Results are identical.  Off by default (a lone
+ * y2_detect_resident call gains nothing and pays two more events); region heads only. */
+void y2_set_detect_overlap(network *net, int on);
 /* Record the forward pass's kernel launches into a hipGraph at the next call and replay it afterwards (one
  * hipGraphLaunch instead of 20-60 launches; for batch-1 callers such as test_detector_img).  The graph is tied to
  * the plan and to the input pointer: a resize / set_batch / mode switch or a different device input re-records.

@@ -40,6 +40,7 @@ void get_region_boxes(layer l, int w, int h, float thresh, float **probs, box *b
     if (!l.output) { y2_fail("get_region_boxes: l.output is NULL"); return; }
     e = d->eng;
     HIPCALL(y2h_set_device(e->device));
+    if (e->det_pending == 1 && e->det_overlap) HIPCALL(y2h_event_sync(e->ev_det));   /* the shared decode scratch is in use on det_stream */
     memset(&q, 0, sizeof q);
     q.batch = 1; q.w = l.w; q.h = l.h; q.num = l.n; q.classes = l.classes;
     q.img_w = w; q.img_h = h; q.thresh = thresh; q.only_objectness = only_objectness; q.classfix = l.classfix;
@@ -282,18 +283,31 @@ static int detect_enqueue(network net, float *d_pred, float thresh, float nms, i
     y2h_decode q;
     const float *final_probs;
     int b, keep;
+    y2h_stream ds;
     if (!e || !e->built) { y2_fail("y2_detect_resident: run a forward first"); return -1; }
     l = &net.layers[e->out_layer];
     d = ld_of(l);
     if (l->type != REGION && l->type != DETECTION) { y2_fail("y2_detect_resident: the network does not end in a region or detection layer"); return -1; }
     HIPCALL_I(y2h_set_device(e->device));
+    if (e->det_pending == 1) HIPCALL_I(y2h_event_sync(e->ev_det));      /* an enqueue that was never fetched: its scratch is ours again */
     e->det_pending = 0;
     if (!e->ev_det) HIPCALL_I(y2h_event_create(&e->ev_det));
+    /* y2_set_detect_overlap (region heads, resident output): the chain runs on its own stream behind an event of the
+     * forward pass that produced d_region; the next forward pass waits for ev_det before its region layer writes
+     * d_region again (enqueue_forward), and nothing else touches the chain's scratch until y2_detect_fetch. */
+    ds = e->stream;
+    if (e->det_overlap && !d_pred && l->type == REGION) {
+        if (!e->det_stream) HIPCALL_I(y2h_stream_create(&e->det_stream));
+        if (!e->ev_fwd) HIPCALL_I(y2h_event_create(&e->ev_fwd));
+        HIPCALL_I(y2h_event_record(e->ev_fwd, e->stream));
+        HIPCALL_I(y2h_stream_wait_event(e->det_stream, e->ev_fwd));
+        ds = e->det_stream;
+    }
     if (!d_pred) d_pred = l->type == REGION ? d->d_region : d->d_flat;
     memset(&q, 0, sizeof q);
     if (l->type == DETECTION) {           /* YOLOv1 head: detection_layer.c:222 decode, then the same NMS / compaction */
         HIPCALL_I(y2h_detection_boxes(d_pred, (long)l->outputs, net.batch, l->side, l->n, l->classes, l->sqrt, img_w, img_h,
-                                      thresh, 0, e->d_boxes, e->d_probs, e->stream));
+                                      thresh, 0, e->d_boxes, e->d_probs, ds));
     } else {
     q.batch = net.batch; q.w = l->w; q.h = l->h; q.num = l->n; q.classes = l->classes;
     q.img_w = img_w; q.img_h = img_h; q.thresh = thresh; q.classfix = l->classfix;
@@ -301,26 +315,26 @@ static int detect_enqueue(network net, float *d_pred, float thresh, float nms, i
     q.tree_parent = l->softmax_tree ? d->d_tree_parent : NULL;
     q.tree_order = d->d_tree_order; q.tree_level_off = d->d_tree_loff; q.tree_levels = d->tree_levels;
     q.pred = d_pred; q.boxes = e->d_boxes; q.probs = e->d_probs;
-    HIPCALL_I(y2h_region_boxes(&q, e->stream));
+    HIPCALL_I(y2h_region_boxes(&q, ds));
     }
     final_probs = e->d_probs;
     if (nms > 0) {
-        HIPCALL_I(y2h_memcpy_d2d(e->d_probs_nms, e->d_probs, (size_t)net.batch * e->det_total * l->classes * sizeof(float), e->stream));
-        HIPCALL_I(y2h_nms_sort(e->d_boxes, e->d_probs, e->d_probs_nms, net.batch, e->det_total, l->classes, l->classes, nms, e->d_class_counts, e->stream));
+        HIPCALL_I(y2h_memcpy_d2d(e->d_probs_nms, e->d_probs, (size_t)net.batch * e->det_total * l->classes * sizeof(float), ds));
+        HIPCALL_I(y2h_nms_sort(e->d_boxes, e->d_probs, e->d_probs_nms, net.batch, e->det_total, l->classes, l->classes, nms, e->d_class_counts, ds));
         final_probs = e->d_probs_nms;
     }
     HIPCALL_I(y2h_collect(e->d_boxes, final_probs, net.batch, e->det_total, l->classes, l->classes, thresh,
-                          e->d_records, e->d_counts, e->det_cap, e->d_best, e->stream));
-    HIPCALL_I(y2h_memcpy_d2h(e->h_counts, e->d_counts, (size_t)net.batch * sizeof(int), e->stream));
+                          e->d_records, e->d_counts, e->det_cap, e->d_best, ds));
+    HIPCALL_I(y2h_memcpy_d2h(e->h_counts, e->d_counts, (size_t)net.batch * sizeof(int), ds));
     keep = 0;
     if ((size_t)net.batch * e->det_cap * 6 * sizeof(float) <= ((size_t)8 << 20)) {
         /* small enough: fetch every record block with the counts, one copy and one sync per batch */
-        HIPCALL_I(y2h_memcpy_d2h(e->h_records, e->d_records, (size_t)net.batch * e->det_cap * 6 * sizeof(float), e->stream));
-        HIPCALL_I(y2h_event_record(e->ev_det, e->stream));
+        HIPCALL_I(y2h_memcpy_d2h(e->h_records, e->d_records, (size_t)net.batch * e->det_cap * 6 * sizeof(float), ds));
+        HIPCALL_I(y2h_event_record(e->ev_det, ds));
         e->det_pending = 1;                   /* detect_fetch waits for the event */
         return 0;
     } else {
-        HIPCALL_I(y2h_stream_sync(e->stream));
+        HIPCALL_I(y2h_stream_sync(ds));
         for (b = 0; b < net.batch; ++b) if (e->h_counts[b] > keep) keep = e->h_counts[b];
         if (keep > e->det_cap) keep = e->det_cap;
     }
@@ -330,9 +344,9 @@ static int detect_enqueue(network net, float *d_pred, float thresh, float nms, i
             int nb = e->h_counts[b] < e->det_cap ? e->h_counts[b] : e->det_cap;
             if (nb > 0)
                 HIPCALL_I(y2h_memcpy_d2h(e->h_records + (size_t)b * e->det_cap * 6, e->d_records + (size_t)b * e->det_cap * 6,
-                                         (size_t)nb * 6 * sizeof(float), e->stream));
+                                         (size_t)nb * 6 * sizeof(float), ds));
         }
-        HIPCALL_I(y2h_stream_sync(e->stream));
+        HIPCALL_I(y2h_stream_sync(ds));
     }
     e->det_pending = 2;                       /* wide heads (yolo9000): fetched synchronously above */
     return 0;
@@ -397,6 +411,7 @@ int y2_detect_mean(network net, float thresh, float nms, int img_w, int img_h, y
     y2_ldev *d;
     size_t els;
     if (!e || !e->built) { y2_fail("y2_detect_mean: run a forward first"); return -1; }
+    if (e->det_pending == 1 && e->det_overlap) HIPCALL_I(y2h_event_sync(e->ev_det));
     l = &net.layers[e->out_layer];
     d = ld_of(l);
     if (l->type != REGION || net.batch != 1) { y2_fail("y2_detect_mean: needs a batch-1 network ending in a region layer"); return -1; }

@@ -152,6 +152,8 @@ void y2_engine_destroy(network *net)
     if (e->ev_det) y2h_event_destroy(e->ev_det);
     if (e->ev_out) y2h_event_destroy(e->ev_out);
     if (e->graph) y2h_graph_destroy(e->graph);
+    if (e->det_stream) y2h_stream_destroy(e->det_stream);
+    if (e->ev_fwd) y2h_event_destroy(e->ev_fwd);
     y2h_stream_destroy(e->stream);
     free(e);
     net->engine = NULL;
@@ -1074,6 +1076,8 @@ static int enqueue_forward(network *net, const float *d_input_nchw)
             break;
         case REGION: {
             tree *t = l->softmax_tree;
+            /* y2_set_detect_overlap: the previous batch's decode / NMS may still be reading d_region on det_stream */
+            if (e->det_overlap && e->det_pending == 1 && i == e->out_layer) HIPCALL(y2h_stream_wait_event(e->stream, e->ev_det));
             HIPCALL(y2h_region_forward(x, ldx, d->d_region, l->batch, l->h * l->w, l->n, l->classes, l->coords, l->softmax,
                                        t ? t->groups : 0, d->d_tree_gsize, d->d_tree_goff, e->stream));
         } break;
@@ -1266,6 +1270,14 @@ void y2_set_autotune(network *net, int on)
 {
     y2_engine *e = y2_engine_of(net);
     if (e) e->autotune = on ? 1 : 0;
+}
+
+void y2_set_detect_overlap(network *net, int on)
+{
+    y2_engine *e = y2_engine_of(net);
+    if (!e) return;
+    if (e->det_pending == 1 && e->ev_det) y2h_event_sync(e->ev_det);     /* nothing of the other mode left in flight */
+    e->det_overlap = on ? 1 : 0;
 }
 
 void y2_set_fusion(network *net, int on)

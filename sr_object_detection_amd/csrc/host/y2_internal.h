@@ -61,6 +61,10 @@ typedef struct y2_engine {
     y2h_event ev_out;          /* recorded behind the output copy of y2_output_enqueue */
     int out_pending;
     y2h_event ev_det;          /* recorded behind the D2H copies of y2_detect_enqueue */
+    /* y2_set_detect_overlap: decode / NMS / compaction of batch i on their own stream beside the forward pass of batch i+1 */
+    int det_overlap;
+    y2h_stream det_stream;
+    y2h_event ev_fwd;          /* recorded on `stream` behind the forward pass whose region output the detect chain reads */
     int det_pending;           /* 1: wait for ev_det in y2_detect_fetch, 2: already fetched synchronously */
     int graph_on;
     y2h_graph graph;

@@ -174,6 +174,7 @@ def lib():
     L.y2_set_half.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_fusion.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_autotune.argtypes = [C.POINTER(CNetwork), C.c_int]
+    L.y2_set_detect_overlap.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_graph.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_set_timing.argtypes = [C.POINTER(CNetwork), C.c_int]
     L.y2_layer_times_ms.argtypes = [CNetwork, C.c_void_p, C.c_int]
@@ -400,6 +401,10 @@ class Network:
 
     def set_fusion(self, on: bool) -> None:
         lib().y2_set_fusion(C.byref(self.net), 1 if on else 0)
+
+    def set_detect_overlap(self, on: bool) -> None:
+        """decode / NMS of batch i on their own stream beside the forward of batch i+1 (include/sr_yolo2.h y2_set_detect_overlap)"""
+        lib().y2_set_detect_overlap(C.byref(self.net), 1 if on else 0)
 
     def set_graph(self, on: bool) -> None:
         """replay the forward pass from a hipGraph (include/sr_yolo2.h y2_set_graph)"""

@@ -173,6 +173,60 @@ def test_detect_enqueue_fetch_overlaps_the_next_forward(workdir):
     net.free()
 
 
+@pytest.mark.parametrize("netname,size,batch", [("mini-mfma", 64, 3), ("yolo", 160, 4)])
+def test_detect_overlap_mode_gives_the_same_detections(workdir, netname, size, batch):
+    """y2_set_detect_overlap: decode / NMS / compaction of batch i on their own stream while batch i+1's forward pass
+    runs -- the next forward must not overwrite the region tensor before the chain has read it (event wait in front of
+    the region layer), and every batch's detections must equal the one-stream run.  Eight different batches through the
+    pipelined loop the benchmark uses, then the plain synchronous call and get_region_boxes with the mode still on."""
+    import os
+    import torch
+    from sr_object_detection_amd import synth, zoo
+    cfg = os.path.join(workdir, "ovl_%s.cfg" % netname)
+    open(cfg, "w").write(zoo.cfg_text(netname, size, size, batch))
+    wts = os.path.join(workdir, "ovl_%s.weights" % netname)
+    synth.write_weights(wts, zoo.resolve(netname, size), 5 if netname == "mini-mfma" else 831)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    frames = [torch.from_numpy(synth.image_batch(batch, 3, size, size, seed=40 + i)).cuda() for i in range(8)]
+    thresh = 0.3 if netname == "mini-mfma" else 0.2
+    want = []
+    for f in frames:
+        net.forward_device(f.data_ptr())
+        want.append(net.detect_resident(thresh, 0.4))
+    assert sum(int(c.sum()) for _, c in want) > 10 and len({int(c.sum()) for _, c in want}) > 1
+    net.set_detect_overlap(True)
+    for rep in range(3):
+        got = []
+        net.forward_device(frames[0].data_ptr())
+        net.detect_enqueue(thresh, 0.4)
+        for i in range(1, 8):
+            net.forward_device(frames[i].data_ptr())
+            got.append(net.detect_fetch())
+            net.detect_enqueue(thresh, 0.4)
+        got.append(net.detect_fetch())
+        for (gd, gc), (wd, wc) in zip(got, want):
+            assert np.array_equal(gc, wc)
+            for a, b in zip(gd, wd):
+                assert np.array_equal(a, b)
+    # the synchronous forms with the mode on
+    net.forward_device(frames[2].data_ptr())
+    gd, gc = net.detect_resident(thresh, 0.4)
+    assert np.array_equal(gc, want[2][1])
+    net.forward_device(frames[3].data_ptr())
+    net.detect_enqueue(thresh, 0.4)
+    out = net.network_predict(frames[3].cpu().numpy())               # a forward + output copy while a chain is pending
+    boxes, probs = net.get_region_boxes(1, 1, thresh, batch_item=0)  # waits for the pending chain before using its scratch
+    gd, gc = net.detect_fetch()
+    assert np.array_equal(gc, want[3][1])
+    assert int((probs.max(axis=1) > thresh).sum()) >= int(gc[0])
+    net.set_detect_overlap(False)
+    net.forward_device(frames[5].data_ptr())
+    gd, gc = net.detect_resident(thresh, 0.4)
+    assert np.array_equal(gc, want[5][1])
+    net.free()
+
+
 def test_output_enqueue_fetch_matches_predict_device(workdir):
     """y2_output_enqueue / y2_output_fetch (the classifier's overlapped host copy): batch i's scores fetched after batch
     i+1's forward was enqueued equal y2_network_predict_device's"""
