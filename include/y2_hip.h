@@ -135,7 +135,7 @@ typedef struct y2h_conv {
     /* tile choice of the matrix-core kernel: 0 = the host's cost model decides (see y2h_conv_candidates) */
     int           tile_bm, tile_bn;   /* GEMM tile (output pixels x filters), one of the instantiated shapes */
     int           ksplit;             /* K ranges per output tile (1 = no split-K) */
-    /* first layer in fp16 mode only: x is the network input itself, fp32 planes [batch][c][h][w] (no NHWC copy) */
+    /* first layer only: x is the network input itself, fp32 planes [batch][c][h][w] (no NHWC copy) */
     int           x_nchw;
 } y2h_conv;
 
@@ -146,8 +146,8 @@ typedef struct y2h_conv {
  * in a fixed order).  Returns the count (0: not an fp32 matrix-core convolution). */
 int y2h_conv_candidates(const y2h_conv *d, int *bm, int *bn, int *ks, int max);
 
-/* 1 if the fp16 first-layer kernel can read the fp32 NCHW network input directly (x_nchw = 1, y_f16 = 1; 3 channels,
- * 3x3/1 pad 1, <= 64 filters, w a multiple of 4): no input transform kernel at all */
+/* 1 if a first-layer kernel can read the fp32 NCHW network input directly (x_nchw = 1; 3 channels, 3x3/1 pad 1,
+ * <= 64 filters; y_f16 as in the descriptor): no input transform kernel at all */
 int y2h_conv_first_layer_nchw_ok(const y2h_conv *d);
 
 /* which kernel y2h_conv_forward would pick: 1 = MFMA implicit GEMM, 0 = direct VALU */

@@ -770,8 +770,9 @@ int y2_engine_build(network *net)
         /* fp16 mode: the first layer reads a half [b][h+2][w+2][4] copy of the input on the fp16 matrix cores */
         if (e->half && ld_of(l0)->out_half && net->c <= 4 && y2h_conv_first_layer_f16_ok(&c0)) e->in_halo = 2;
         /* ... or, where the shape allows, reads the fp32 planes of the network input directly: no transform kernel */
-        if (e->in_halo == 2) {
+        if (e->in_halo == 2 || (e->in_halo == 1 && e->in_halo_px == 1 && y2h_conv_first_layer_ok(&c0))) {
             c0.fuse_maxpool2 = ld_of(l0)->fused_pool;
+            c0.y_f16 = ld_of(l0)->out_half;
             c0.x = (const float *)(uintptr_t)256;
             if (y2h_conv_first_layer_nchw_ok(&c0)) e->in_halo = 3;
         }
@@ -1015,7 +1016,7 @@ static int enqueue_forward(network *net, const float *d_input_nchw)
     e->cur_input = d_input_nchw;
     if (e->in_halo == 3 && ((uintptr_t)d_input_nchw % 16) == 0)
         ;                                                       /* the first layer reads d_input_nchw */
-    else if (e->in_halo == 3) { y2_fail("the fp16 first layer needs a 16-byte aligned network input"); return -1; }
+    else if (e->in_halo == 3) { y2_fail("the first layer needs a 16-byte aligned network input"); return -1; }
     else if (e->in_halo == 2)
         HIPCALL(y2h_nchw_to_nhwc4_halo_f16(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, e->stream));
     else if (e->in_halo)

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
 
     float bw[NT][14];
-    unsigned delta[14];
+    unsigned delta[14], tapbit[14];
 #pragma unroll
     for (int t = 0; t < 14; ++t) {
         const int k = 2 * t + lh;
@@ -570,6 +570,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
         const int tap = kk / 3, ci = kk - tap * 3;
         const int kh = tap / 3, kw = tap - kh * 3;
         delta[t] = (unsigned)(((kh * W2 + kw) * a.ldx + ci) * 4);
+        // a.nchw: x is the network input itself, fp32 planes [batch][3][H][W], no halo: the tap's offset from the lane's
+        // pixel in plane 0 (may be negative: unsigned wrap-around), and the tap's bit in the lane's validity mask
+        if (a.nchw) delta[t] = (unsigned)(((ci * a.H + kh - 1) * a.W + (kw - 1)) * 4);
+        tapbit[t] = 1u << tap;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int co = j * 32 + li;
@@ -607,11 +611,33 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
     }
     auto load_tile = [&](float (&av)[14]) {
         const int py = a.pool ? 2 * cy + ((li >> 1) & 1) : cy, px = a.pool ? 2 * cx + (li & 1) : cx;
-        // rows past the end read out of range: zeros, no traffic (their results are never stored)
-        const unsigned base = (unit < nunits) ? ((unsigned)(cn * H2 + py) * (unsigned)W2 + (unsigned)px) * (unsigned)a.ldx * 4u : a.xbytes;
+        const bool live = unit < nunits;
+        const int cn0 = cn;
         unit += ustep;
         cx += ustep;
         while (cx >= Wu) { cx -= Wu; if (++cy >= Hu) { cy = 0; ++cn; } }
+        if (a.nchw) {
+            // No halo to lean on: taps outside the image must read as zero.  A tile whose 32 pixels all lie in the interior
+            // (nine of ten) needs no per-tap test; otherwise tap (kh, kw) is valid iff row bit kh and column bit kw are set.
+            const unsigned pbase = live ? (((unsigned)cn0 * 3u * (unsigned)a.H + (unsigned)py) * (unsigned)a.W + (unsigned)px) * 4u : a.xbytes;
+            const bool inner = !live || (py > 0 && py < a.H - 1 && px > 0 && px < a.W - 1);
+            if (__builtin_amdgcn_ballot_w64(!inner) == 0) {
+#pragma unroll
+                for (int t = 0; t < 14; ++t)
+                    av[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, live ? pbase + delta[t] : a.xbytes, 0, 0));
+            } else {
+                const unsigned rm = (py > 0 ? 1u : 0u) | 2u | (py < a.H - 1 ? 4u : 0u);
+                const unsigned cm = (px > 0 ? 1u : 0u) | 2u | (px < a.W - 1 ? 4u : 0u);
+                // bit 3 kh + kw = row bit kh & column bit kw
+                const unsigned tm = live ? ((rm & 1u ? cm : 0u) | (rm & 2u ? cm << 3 : 0u) | (rm & 4u ? cm << 6 : 0u)) : 0u;
+#pragma unroll
+                for (int t = 0; t < 14; ++t)
+                    av[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (tm & tapbit[t]) ? pbase + delta[t] : a.xbytes, 0, 0));
+            }
+            return;
+        }
+        // rows past the end read out of range: zeros, no traffic (their results are never stored)
+        const unsigned base = live ? ((unsigned)(cn0 * H2 + py) * (unsigned)W2 + (unsigned)px) * (unsigned)a.ldx * 4u : a.xbytes;
 #pragma unroll
         for (int t = 0; t < 14; ++t)
             av[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, base == a.xbytes ? base : base + delta[t], 0, 0));
@@ -1074,6 +1100,16 @@ static bool first_ok(const y2h_conv *d)
     return xbytes < 4294967000.0 && d->w_packed != nullptr;
 }
 
+// the same kernel reading the fp32 NCHW network input itself (x_nchw = 1): no halo, border taps masked per tile
+static bool first_nchw_ok(const y2h_conv *d)
+{
+    if (!d->x_nchw || d->x_f16 || d->x_halo) return false;
+    if (d->c != 3 || d->size != 3 || d->stride != 1 || d->pad != 1 || d->n > 64) return false;
+    if (d->out_h != d->h || d->out_w != d->w || getenv("Y2_NO_FIRST_NCHW")) return false;
+    const double xbytes = (double)d->batch * 3.0 * d->h * d->w * 4.0;
+    return xbytes < 4294967000.0 && d->w_packed != nullptr;
+}
+
 // stem kernel: Cin <= 4, any size / stride, the halo equal to the padding, <= 128 filters, tables within the LDS
 static size_t stem_lds_bytes(const y2h_conv *d)
 {
@@ -1119,21 +1155,26 @@ extern "C" int y2h_conv_first_layer_f16_ok(const y2h_conv *d)
 extern "C" int y2h_conv_first_layer_nchw_ok(const y2h_conv *d)
 {
     y2h_conv t = *d;
-    t.x_halo = 0; t.x_f16 = 0; t.x_nchw = 1; t.y_f16 = 1;
+    t.x_halo = 0; t.x_f16 = 0; t.x_nchw = 1;
     if (!t.x) t.x = (const float *)(uintptr_t)256;
-    return y2_f16_first_nchw_ok(&t) ? 1 : 0;
+    if (!t.w_packed) t.w_packed = (const float *)(uintptr_t)256;
+    return (t.y_f16 ? y2_f16_first_nchw_ok(&t) || first_nchw_ok(&t) : first_nchw_ok(&t)) ? 1 : 0;
 }
 
 extern "C" int y2h_conv_uses_mfma(const y2h_conv *d)
 {
-    if (d->x_nchw) return y2_f16_first_nchw_ok(d) ? 1 : 0;
+    if (d->x_nchw) return (y2_f16_first_nchw_ok(d) || first_nchw_ok(d)) ? 1 : 0;
     if (d->x_f16) return (y2_f16_first_ok(d) || y2_f16_conv_ok(d)) ? 1 : 0;
     return first_ok(d) || (d->x_halo == 0 && mfma_ok(d) && pick_variant(d)) || (d->c <= 4 && stem_ok(d)) ? 1 : 0;
 }
 
 extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
 {
-    if (d->x_nchw) return (!strict && y2_f16_first_nchw_ok(d)) ? (d->n <= 32 ? "conv_first_mfma_f16_nchw_c3_n32" : "conv_first_mfma_f16_nchw_c3_n64") : nullptr;
+    if (d->x_nchw) {
+        if (!strict && y2_f16_first_nchw_ok(d)) return d->n <= 32 ? "conv_first_mfma_f16_nchw_c3_n32" : "conv_first_mfma_f16_nchw_c3_n64";
+        if (!strict && first_nchw_ok(d)) return d->n <= 32 ? "conv_first_mfma_f32_nchw_c3_n32" : "conv_first_mfma_f32_nchw_c3_n64";
+        return nullptr;
+    }
     if (!strict && first_ok(d)) return d->n <= 32 ? "conv_first_mfma_f32_c3_n32" : "conv_first_mfma_f32_c3_n64";
     if (d->x_f16) {
         if (!strict && y2_f16_first_ok(d)) return d->n <= 32 ? "conv_first_mfma_f16_c3_n32" : "conv_first_mfma_f16_c3_n64";
@@ -1168,9 +1209,21 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
 
     if (d->x_nchw) {
         // the network input itself (fp32 planes): only the fused fp16 first-layer kernel reads that layout
-        if (strict || !y2_f16_first_nchw_ok(d)) return Y2H_EINVAL;
+        if (strict || !(y2_f16_first_nchw_ok(d) || first_nchw_ok(d))) return Y2H_EINVAL;
+        if (d->fuse_maxpool2 && ((d->h | d->w) & 1)) return Y2H_EINVAL;
         a.pool = d->fuse_maxpool2 ? 1 : 0;
-        return y2_f16_first_nchw_launch(d, a, s);
+        if (y2_f16_first_nchw_ok(d)) return y2_f16_first_nchw_launch(d, a, s);
+        a.nchw = 1;
+        a.w = d->w_packed;
+        a.npix = d->batch * d->h * d->w;
+        a.xbytes = (unsigned)((size_t)d->batch * 3 * d->h * d->w * 4);
+        const long ntiles = ((long)a.npix + 31) / 32;
+        long blocks = (ntiles + 3) / 4;
+        if (blocks > 256 * 4) blocks = 256 * 4;
+        if (d->n <= 32) hipLaunchKernelGGL(conv_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+        else hipLaunchKernelGGL(conv_first_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+        Y2H_LAUNCH_CHECK();
+        return Y2H_OK;
     }
     if (d->fuse_maxpool2) {
         // only the matrix-core kernels pool in their epilogue, and 2x2/2 windows need even dims

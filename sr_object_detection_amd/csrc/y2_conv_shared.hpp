@@ -20,6 +20,7 @@ struct ConvK {
     const float *alpha, *beta;   // fp16 path: y = act(acc * alpha[co] + beta[co])
     int y_f16;         // 1: the output is stored as IEEE half
     int vec_store;     // fp16 kernels: half outputs leave as 16-byte stores (ldy, y and Cout aligned to 8 halves)
+    int nchw;          // first-layer kernel: x is the fp32 NCHW network input (no halo, no NHWC copy)
     int dbg;           // ablation switches for tuning runs (env Y2_DBG; 0 in normal use): see y2_conv_f16.hip
     int H, W, Cin, ldx, Cout, ldy, K;
     int npix;          // GEMM rows = output pixels: batch * out_h * out_w (== batch * H * W at stride 1)

@@ -171,11 +171,18 @@ def test_pooled_epilogue_with_negative_scales(oracle, workdir, monkeypatch, tile
     assert (ref < 0).any() and (ref > 0).any()
 
 
-def test_first_layer_pooled_epilogue_with_negative_scales(oracle, workdir):
-    """the 3-channel first-layer kernel (conv_first_kernel, pipelined batch-norm + leaky copy and generic copy)"""
-    for act in ("leaky", "linear"):
+@pytest.mark.parametrize("direct", [True, False], ids=["nchw", "halo"])
+def test_first_layer_pooled_epilogue_with_negative_scales(oracle, workdir, monkeypatch, direct):
+    """the 3-channel first-layer kernel (conv_first_kernel, pipelined batch-norm + leaky copy and generic copy), reading
+    the NCHW network input itself (border taps masked per tile; 38 = a size that is no multiple of the 32-pixel tile) and
+    in its older form behind the NHWC + halo transform: the same bits"""
+    if direct:
+        monkeypatch.delenv("Y2_NO_FIRST_NCHW", raising=False)
+    else:
+        monkeypatch.setenv("Y2_NO_FIRST_NCHW", "1")
+    for act, size in (("leaky", 40), ("linear", 40), ("leaky", 38)):
         spec = [("conv", 32, 3, 1, act), ("max", 2, 2)]
-        cfg, wts, x = _small_int_conv_case(workdir, spec, 40, 3, 62000 + len(act), neg_scale=True)
+        cfg, wts, x = _small_int_conv_case(workdir, spec, size, 3, 62000 + len(act) + size, neg_scale=True)
         on = oracle.OracleNet(cfg, wts)
         ref = on.predict(x)
         outs = []
@@ -184,11 +191,29 @@ def test_first_layer_pooled_epilogue_with_negative_scales(oracle, workdir):
             net.load_weights(wts)
             net.set_fusion(fuse)
             outs.append(net.network_predict(x).copy())
-            assert net.layer_kernel(0).startswith("conv_first_mfma_f32") and ("+maxpool2" in net.layer_kernel(0)) == fuse
+            want = "conv_first_mfma_f32_nchw_c3_n32" if direct else "conv_first_mfma_f32_c3_n32"
+            assert net.layer_kernel(0) == want + ("+maxpool2" if fuse else ""), net.layer_kernel(0)
             net.free()
         on.close()
         assert np.array_equal(outs[0], outs[1])
         assert np.abs(outs[0] - ref).max() <= np.abs(ref).max() * 2.0 ** -23
+
+
+def test_first_layer_from_nchw_is_exact_on_integer_data(oracle, workdir, monkeypatch):
+    """fp32 first layer without batch-norm on integer data: every border tap masked correctly <=> equal to the oracle"""
+    monkeypatch.delenv("Y2_NO_FIRST_NCHW", raising=False)
+    for filters, size, batch in ((32, 38, 2), (48, 33, 3), (16, 64, 1)):
+        spec = [("conv", filters, 3, 0, "linear")]
+        cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 63000 + filters + size)
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        out = net.network_predict(x)
+        assert net.layer_kernel(0).startswith("conv_first_mfma_f32_nchw_c3_n")
+        net.free()
+        on = oracle.OracleNet(cfg, wts)
+        ref = on.predict(x)
+        on.close()
+        assert np.array_equal(out, ref)
 
 
 @pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
