@@ -253,15 +253,17 @@ __global__ __launch_bounds__(256) void class_count_kernel(const float *__restric
     }
 }
 
+#define NMS_LDS_BOXES 1024
 __global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ pin_all,
                                                        float *__restrict__ pout_all, const int *__restrict__ class_counts,
-                                                       int total, int classes, int stride, float thresh, int cap)
+                                                       int total, int classes, int stride, float thresh, int cap, int lds_boxes)
 {
     if (class_counts[blockIdx.x] < 2) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
     unsigned long long *keys = (unsigned long long *)nms_smem;          // [cap]
     unsigned char *dead = (unsigned char *)(keys + cap);                // [cap]
     __shared__ int s_count;
+    float4 *s_box = (float4 *)(nms_smem + (((size_t)cap * 9 + 15) & ~(size_t)15));      // [lds_boxes], behind keys and flags
 
     const int k = blockIdx.x % classes;
     const int b = blockIdx.x / classes;
@@ -321,7 +323,21 @@ __global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__
         }
     }
     __syncthreads();
-    // greedy suppression in sorted order
+    // greedy suppression in sorted order.  The walk is n - 1 dependent rounds; with the boxes fetched from global memory
+    // inside each round a round costs a memory latency (62 us per 32 frames of yolo.cfg 608 for ~30 candidates of the
+    // busiest class), so up to NMS_LDS_BOXES candidates are gathered into LDS once, in sorted order.
+    if (n <= lds_boxes) {
+        for (int j = t; j < n; j += 256) s_box[j] = *(const float4 *)(bx + (size_t)(~(unsigned)(keys[j] & 0xffffffffull)) * 4);
+        __syncthreads();
+        for (int i = 0; i < n - 1; ++i) {
+            if (!dead[i]) {
+                const float4 a = s_box[i];
+                for (int j = i + 1 + t; j < n; j += 256)
+                    if (box_iou_f(a, s_box[j]) > thresh) dead[j] = 1;
+            }
+            __syncthreads();
+        }
+    } else
     for (int i = 0; i < n - 1; ++i) {
         if (!dead[i]) {                      // uniform: every lane reads the same LDS byte
             const unsigned ia = ~(unsigned)(keys[i] & 0xffffffffull);
@@ -350,7 +366,8 @@ extern "C" int y2h_nms_sort(const float *boxes, const float *probs_in, float *pr
     if (total > 16384) return Y2H_EINVAL;            // LDS holds every candidate of one class
     int cap = 1;
     while (cap < total) cap <<= 1;
-    const size_t lds = (size_t)cap * 9;
+    const int lds_boxes = cap <= 8192 ? NMS_LDS_BOXES : 0;           // 16384 candidates fill the LDS by themselves
+    const size_t lds = (((size_t)cap * 9 + 15) & ~(size_t)15) + (size_t)lds_boxes * 16;
     static bool attr_set[16] = {false};
     int dev = 0;
     Y2H_CHECK(hipGetDevice(&dev));
@@ -364,7 +381,7 @@ extern "C" int y2h_nms_sort(const float *boxes, const float *probs_in, float *pr
                        probs_in, class_counts, total, classes, stride, nel);
     Y2H_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)(batch * classes)), dim3(256), lds, S(s),
-                       boxes, probs_in, probs, class_counts, total, classes, stride, thresh, cap);
+                       boxes, probs_in, probs, class_counts, total, classes, stride, thresh, cap, lds_boxes);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }

@@ -286,27 +286,54 @@ __global__ __launch_bounds__(256) void region_tree_kernel(const float *__restric
 // reference), but the rows of the 64 boxes of a workgroup travel through LDS (a box is `size` consecutive floats;
 // thread-strided access to them cost 93 us per 32 frames of yolo.cfg 608).  size is odd for the cfgs of the family
 // (85, 25, 30), so the per-thread LDS rows do not collide on banks.
-__global__ __launch_bounds__(64) void region_lds_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
-                                                        long boxes, int num, int classes, int coords, int softmax)
+__global__ __launch_bounds__(256) void region_lds_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
+                                                         long boxes, int num, int classes, int coords, int softmax)
 {
-    extern __shared__ float rows[];                        // [64][size]
+    extern __shared__ float rows[];                        // [64][size] + [64] largest + [64] sum
     const int size = coords + 1 + classes;
     const long b0 = (long)blockIdx.x * 64;
     const int nb = (boxes - b0 < 64) ? (int)(boxes - b0) : 64;
-    for (int idx = threadIdx.x; idx < nb * size; idx += 64) {
+    float *s_max = rows + 64 * size, *s_sum = s_max + 64;
+    const int t = threadIdx.x;
+    for (int idx = t; idx < nb * size; idx += 256) {
         const int bx = idx / size, k = idx - bx * size;
         const long i = b0 + bx;
         rows[idx] = x[(i / num) * ldx + (long)(i % num) * size + k];
     }
     __syncthreads();
-    if ((int)threadIdx.x < nb) {
-        float *r = rows + (size_t)threadIdx.x * size;
+    // The double-precision exponentials (all of the time: 80 per box) are independent, so every thread takes a share; only
+    // the running fp32 sum, whose order the reference fixes (softmax_seq), is walked by one thread per box.  Same values,
+    // same order, same bits as one thread per box doing everything (45 -> 15 us per 32 frames of yolo.cfg 608).
+    if (t < nb) {
+        float *r = rows + (size_t)t * size;
         r[coords] = (float)(1. / (1. + exp(-(double)r[coords])));
-        if (softmax == 1) softmax_seq(r + coords + 1, classes, 1.f, r + coords + 1);
+        float largest = -FLT_MAX;
+        if (softmax == 1) for (int k = 0; k < classes; ++k) if (r[coords + 1 + k] > largest) largest = r[coords + 1 + k];
+        s_max[t] = largest;
+    }
+    if (softmax == 1) {
+        __syncthreads();
+        for (int idx = t; idx < nb * classes; idx += 256) {
+            const int bx = idx / classes, k = idx - bx * classes;
+            float *v = rows + (size_t)bx * size + coords + 1 + k;
+            *v = (float)exp((double)(*v / 1.f - s_max[bx] / 1.f));
+        }
+        __syncthreads();
+        if (t < nb) {
+            const float *r = rows + (size_t)t * size + coords + 1;
+            float sum = 0.f;
+            for (int k = 0; k < classes; ++k) sum += r[k];
+            s_sum[t] = sum;
+        }
+        __syncthreads();
+        for (int idx = t; idx < nb * classes; idx += 256) {
+            const int bx = idx / classes, k = idx - bx * classes;
+            rows[(size_t)bx * size + coords + 1 + k] /= s_sum[bx];
+        }
     }
     __syncthreads();
     float *dst = y + b0 * size;
-    for (int idx = threadIdx.x; idx < nb * size; idx += 64) dst[idx] = rows[idx];
+    for (int idx = t; idx < nb * size; idx += 256) dst[idx] = rows[idx];
 }
 
 // Same arithmetic, one workgroup per box: the class scores of the box are staged through LDS with coalesced
@@ -338,9 +365,9 @@ extern "C" int y2h_region_forward(const float *x, int ldx, float *y, int batch, 
     if (ldx < num * (coords + 1 + classes)) return Y2H_EINVAL;
     const long boxes = (long)batch * hw * num;
     const int mode = groups > 0 ? 2 : (softmax ? 1 : 0);
-    const size_t row_bytes = (size_t)64 * (coords + 1 + classes) * sizeof(float);
+    const size_t row_bytes = ((size_t)64 * (coords + 1 + classes) + 128) * sizeof(float);
     if (mode != 2 && row_bytes <= 64 * 1024)
-        hipLaunchKernelGGL(region_lds_kernel, dim3((unsigned)((boxes + 63) / 64)), dim3(64), row_bytes, S(s),
+        hipLaunchKernelGGL(region_lds_kernel, dim3((unsigned)((boxes + 63) / 64)), dim3(256), row_bytes, S(s),
                            x, ldx, y, boxes, num, classes, coords, mode);
     else    // tree heads (their class scores are rewritten by the tree kernel below) and very wide rows
         hipLaunchKernelGGL(region_kernel, dim3((unsigned)((boxes + 63) / 64)), dim3(64), 0, S(s),
