@@ -3,6 +3,9 @@
 // (src_yolo2/cuda.c:12-160); unlike it, nothing here aborts -- errors come
 // back as codes and the text is kept for y2h_last_error().
 #include "y2_common.hpp"
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 static char g_name[256] = "";
@@ -33,8 +36,66 @@ extern "C" const char *y2h_device_name(void)
     return g_name;
 }
 
-extern "C" int y2h_malloc(void **ptr, size_t bytes) { Y2H_CHECK(hipMalloc(ptr, bytes ? bytes : 16)); return Y2H_OK; }
-extern "C" int y2h_free(void *ptr) { if (ptr) Y2H_CHECK(hipFree(ptr)); return Y2H_OK; }
+// Debug aid (env Y2_GUARD=1, e.g. for a whole `pytest -m gpu` run): every device buffer gets a 4 KB canary in front of and
+// behind it, filled with 0xA5 at allocation and checked when the buffer is freed (hipFree has waited for the device by
+// then); a kernel that wrote outside its buffer is reported with the buffer's size and the first damaged offset.  Off, the
+// two functions are plain hipMalloc / hipFree.
+namespace {
+constexpr size_t GUARD = 4096;
+std::mutex g_guard_mu;
+std::unordered_map<void *, size_t> g_guarded;         // user pointer -> user bytes
+bool guard_on()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("Y2_GUARD"); on = (e && atoi(e) != 0) ? 1 : 0; }
+    return on == 1;
+}
+}
+
+extern "C" int y2h_malloc(void **ptr, size_t bytes)
+{
+    if (!guard_on()) { Y2H_CHECK(hipMalloc(ptr, bytes ? bytes : 16)); return Y2H_OK; }
+    const size_t user = ((bytes ? bytes : 16) + 255) & ~(size_t)255;
+    unsigned char *base = nullptr;
+    Y2H_CHECK(hipMalloc((void **)&base, user + 2 * GUARD));
+    Y2H_CHECK(hipMemset(base, 0xA5, GUARD));
+    Y2H_CHECK(hipMemset(base + GUARD + (bytes ? bytes : 16), 0xA5, user - (bytes ? bytes : 16) + GUARD));
+    *ptr = base + GUARD;
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guarded[*ptr] = bytes ? bytes : 16;
+    return Y2H_OK;
+}
+
+extern "C" int y2h_free(void *ptr)
+{
+    if (!ptr) return Y2H_OK;
+    if (!guard_on()) { Y2H_CHECK(hipFree(ptr)); return Y2H_OK; }
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guarded.find(ptr);
+        if (it == g_guarded.end()) { Y2H_CHECK(hipFree(ptr)); return Y2H_OK; }       // allocated before the switch was read
+        bytes = it->second;
+        g_guarded.erase(it);
+    }
+    const size_t user = (bytes + 255) & ~(size_t)255;
+    unsigned char *base = (unsigned char *)ptr - GUARD;
+    std::vector<unsigned char> h(user + 2 * GUARD);
+    Y2H_CHECK(hipDeviceSynchronize());
+    Y2H_CHECK(hipMemcpy(h.data(), base, GUARD, hipMemcpyDeviceToHost));
+    Y2H_CHECK(hipMemcpy(h.data() + GUARD + bytes, base + GUARD + bytes, user - bytes + GUARD, hipMemcpyDeviceToHost));
+    long bad_front = -1, bad_back = -1;
+    for (size_t i = 0; i < GUARD; ++i) if (h[GUARD - 1 - i] != 0xA5) { bad_front = (long)i + 1; break; }
+    for (size_t i = GUARD + bytes; i < user + 2 * GUARD; ++i) if (h[i] != 0xA5) { bad_back = (long)(i - GUARD - bytes); break; }
+    Y2H_CHECK(hipFree(base));
+    if (bad_front >= 0 || bad_back >= 0) {
+        fprintf(stderr, "Y2_GUARD: a kernel wrote outside a device buffer of %zu bytes: %ld bytes in front of it / %ld bytes past its end (-1 = intact)\n",
+                bytes, bad_front, bad_back);
+        y2h_set_error_("Y2_GUARD", "write outside a device buffer");
+        return Y2H_EHIP;
+    }
+    return Y2H_OK;
+}
 extern "C" int y2h_host_alloc(void **ptr, size_t bytes) { Y2H_CHECK(hipHostMalloc(ptr, bytes ? bytes : 16, hipHostMallocDefault)); return Y2H_OK; }
 extern "C" int y2h_host_free(void *ptr) { if (ptr) Y2H_CHECK(hipHostFree(ptr)); return Y2H_OK; }
 extern "C" int y2h_host_register(void *ptr, size_t bytes) { Y2H_CHECK(hipHostRegister(ptr, bytes, hipHostRegisterDefault)); return Y2H_OK; }
