@@ -25,7 +25,11 @@ def load(d, tag):
         k = int(x["Dispatch_Id"])
         if k in rows:
             rows[k]["us"] = (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3
-    ids = [k for k in rows if "nchw_to_nhwc" in rows[k]["name"]]
+    # first launch of a step: the input transform where the plan has one, else the first-layer kernel (which reads the
+    # NCHW input itself)
+    ids = [k for k in rows if "nchw_to_nhwc" in rows[k]["name"]] or [k for k in rows if "conv_first" in rows[k]["name"]]
+    if not ids:
+        sys.exit("no step marker (input transform / first-layer kernel) among the profiled kernels")
     want_conv = not OTHER
     return [rows[k] for k in rows if k >= ids[-1] and (("conv" in rows[k]["name"]) == want_conv)]
 
