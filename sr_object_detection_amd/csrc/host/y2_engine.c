@@ -74,7 +74,6 @@ void y2_engine_host_output(network *net)
     ol = &net->layers[e->out_layer];
     need = (size_t)net->batch * ol->outputs;
     if (need > e->h_out_cap || !e->h_out) {
-        if (e->h_out_pinned) { y2h_host_unregister(e->h_out); e->h_out_pinned = 0; }
         free(e->h_out);
         e->h_out = NULL;
         if (posix_memalign((void **)&e->h_out, 4096, (need ? need : 1) * sizeof(float)) != 0) e->h_out = NULL;
@@ -146,7 +145,7 @@ void y2_engine_destroy(network *net)
         net->layers[i].dev = NULL;
     }
     y2h_free(e->arena);
-    if (e->h_out_pinned) y2h_host_unregister(e->h_out);
+    y2h_host_free(e->h_out_stage);
     free(e->h_out);
     if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
     if (e->ev_det) y2h_event_destroy(e->ev_det);
@@ -308,8 +307,12 @@ static unsigned short f32_to_f16_rne(float f)
 static int upload_weights(network *net)
 {
     y2_engine *e = y2_engine_of(net);
-    unsigned char *host = calloc(1, e->arena_bytes ? e->arena_bytes : 16);
+    /* pinned staging: no pageable buffer of ours is ever handed to an asynchronous copy */
+    unsigned char *host = NULL;
+    if (y2h_host_alloc((void **)&host, e->arena_bytes ? e->arena_bytes : 16) != 0) host = NULL;
     int i;
+    if (!host) { y2_fail("weight upload: no pinned host memory for %zu bytes: %s", e->arena_bytes, y2h_last_error()); return -1; }
+    memset(host, 0, e->arena_bytes ? e->arena_bytes : 16);
     for (i = 0; i < net->n; ++i) {
         const layer *l = &net->layers[i];
         const y2_ldev *d = ld_of(l);
@@ -408,11 +411,11 @@ static int upload_weights(network *net)
         }
     }
     if (y2h_memcpy_h2d(e->arena, host, e->arena_bytes, e->stream) != 0 || y2h_stream_sync(e->stream) != 0) {
-        free(host);
+        y2h_host_free(host);
         y2_fail("weight upload failed: %s", y2h_last_error());
         return -1;
     }
-    free(host);
+    y2h_host_free(host);
     e->weights_dirty = 0;
     return 0;
 }
@@ -790,7 +793,11 @@ int y2_engine_build(network *net)
         e->out_floats = (size_t)net->batch * ol->outputs;
         y2_engine_host_output(net);
         if (!e->h_out) { y2_fail("out of host memory for the network output"); return -1; }
-        if (!e->h_out_pinned && y2h_host_register(e->h_out, e->h_out_cap * sizeof(float)) == 0) e->h_out_pinned = 1;
+        if (e->out_floats > e->h_out_stage_cap) {
+            y2h_host_free(e->h_out_stage); e->h_out_stage = NULL; e->h_out_stage_cap = 0;
+            HIPCALL(y2h_host_alloc((void **)&e->h_out_stage, e->out_floats * sizeof(float)));
+            e->h_out_stage_cap = e->out_floats;
+        }
         HIPCALL(y2h_malloc((void **)&e->d_out_nchw, e->out_floats * sizeof(float)));
         if (ol->type == REGION || ol->type == DETECTION) {
             e->det_total = ol->w * ol->h * ol->n;         /* a [detection] layer has w = h = side */
@@ -1179,8 +1186,9 @@ int y2_engine_fetch_output(network *net)
             HIPCALL(y2h_nhwc_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
         src = e->d_out_nchw;
     }
-    HIPCALL(y2h_memcpy_d2h(e->h_out, src, e->out_floats * sizeof(float), e->stream));
+    HIPCALL(y2h_memcpy_d2h(e->h_out_stage, src, e->out_floats * sizeof(float), e->stream));
     HIPCALL(y2h_stream_sync(e->stream));
+    memcpy(e->h_out, e->h_out_stage, e->out_floats * sizeof(float));
     return 0;
 }
 
@@ -1204,7 +1212,7 @@ int y2_output_enqueue(network net)
             HIPCALL(y2h_nhwc_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
         src = e->d_out_nchw;
     }
-    HIPCALL(y2h_memcpy_d2h(e->h_out, src, e->out_floats * sizeof(float), e->stream));
+    HIPCALL(y2h_memcpy_d2h(e->h_out_stage, src, e->out_floats * sizeof(float), e->stream));
     HIPCALL(y2h_event_record(e->ev_out, e->stream));
     e->out_pending = 1;
     return 0;
@@ -1216,6 +1224,7 @@ float *y2_output_fetch(network net)
     if (!e || !e->out_pending) { y2_fail("y2_output_fetch: nothing was enqueued (call y2_output_enqueue after a forward)"); return NULL; }
     if (y2h_event_sync(e->ev_out) != 0) { y2_fail("y2_output_fetch: %s", y2h_last_error()); return NULL; }
     e->out_pending = 0;
+    memcpy(e->h_out, e->h_out_stage, e->out_floats * sizeof(float));
     return e->h_out;
 }
 

@@ -91,7 +91,11 @@ typedef struct y2_engine {
                                   l.output (callers copy `layer` structs early), pinned once a GPU is in use */
     size_t out_floats;
     size_t h_out_cap;          /* floats allocated behind h_out */
-    int h_out_pinned;
+    float *h_out_stage;        /* pinned (hipHostMalloc) landing buffer of the output copy, out_floats long; h_out itself is
+                                  plain heap memory and is never handed to the GPU: registering it in place
+                                  (hipHostRegister) made the runtime treat a pageable buffer that starts in the page behind
+                                  it as part of the registration -- the next weight upload from such a buffer faulted */
+    size_t h_out_stage_cap;
     int out_layer;
     /* decode / nms buffers for the output region layer */
     float *d_boxes, *d_probs, *d_probs_nms, *d_records;

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 }
 
 // ---------------------------------------------------------------------------
-// 256x256x64 tile, LDS-DMA staging, eight phases per two K-tiles (the dominant fp16 kernel).
+// 256x256x64 tile, LDS-DMA staging, two 32-MFMA phases per K-tile (the dominant fp16 kernel).
 //
 // The register-staged kernel above spends its K loop at about twice its pure-MFMA time: per K-tile every thread
 // issues 8 buffer loads, holds them in 32 VGPRs, writes them to LDS with 8 ds_write_b128 and the whole workgroup meets
@@ -461,17 +461,16 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
 //     writes zeros (tools/probes/glds_oob.hip).
 //   * a K-tile (64 channels of one tap) is four half-tiles of 16 KB -- A-h0 (GEMM rows 0..127), B-h0 (filters 0..127),
 //     B-h1, A-h1 -- in one of two 64 KB buffers.  A wave (wm, wn) owns rows {64 wm .. +64} of EACH A half and filters
-//     {32 wn .. +32} of EACH B half, so its 128 x 64 output is four quadrants (A half, B half) and a K-tile is four
-//     phases of 16 v_mfma_f32_16x16x32_f16 each: (A0,B0) (A0,B1) (A1,B1) (A1,B0).  A phase reads only the fragments it
-//     introduces (A0+B0: 12 ds_read_b128, B1: 4, A1: 8, none) and issues the DMA of ONE half-tile, five half-tiles ahead
-//     of the half-tile first read in it, across K-tile and tile boundaries (persistent workgroups).
-//   * phase = { fragment reads, 2 DMA, s_waitcnt vmcnt(6) } s_barrier { lgkmcnt(0), 16 MFMA } s_barrier.  vmcnt(6)
-//     leaves three half-tiles in flight and retires the one first read in the NEXT phase; the waits never drain
-//     (raw s_barrier: __syncthreads() would add vmcnt(0)).  Waves 4..7 run one barrier behind waves 0..3, so on every
-//     SIMD one wave is in its matrix segment while its partner reads fragments and issues DMA.
-//     Hazards, counted in phases: a half-tile is read >= 1 phase after the wait + barrier that retire it (read-after-
-//     write), and a slot is re-filled >= 3 phases after its last fragment read (write-after-read; 2 are needed with the
-//     one-barrier skew between the wave groups).
+//     {32 wn .. +32} of EACH B half, so its 128 x 64 output is four quadrants (A half, B half) of 16
+//     v_mfma_f32_16x16x32_f16 each, and a K-tile is two phases: A-h0 against both B halves, then A-h1 against both.
+//   * phase = { fragment reads, DMA of the next K-tile's half-tiles, counted s_waitcnt vmcnt } s_barrier
+//     { lgkmcnt(0), 32 MFMA } s_barrier (see the `phase` lambda for the counts).  The waits never drain (raw s_barrier:
+//     __syncthreads() would add vmcnt(0)); staging runs across K-tile and tile boundaries (persistent workgroups).
+//     Waves 4..7 run one barrier behind waves 0..3, so on every SIMD one wave is in its matrix segment while its
+//     partner reads fragments and issues DMA (without the skew the kernel is 20 % slower).
+//     Hazards, in barriers: a half-tile is read >= 1 barrier after the wait + barrier that retire it for every wave
+//     (read-after-write), and a slot is re-filled >= 4 barriers after its last fragment read (write-after-read; one
+//     barrier of that is eaten by the skew between the wave groups).
 //   * the epilogue is the 16x16-tile one of the register-staged kernel (folded batch-norm, activation, optional 2x2
 //     maxpool over the four accumulator registers of a lane, 16-byte stores through a wave-private LDS transpose) with
 //     its own 20 KB of LDS, so it never touches a buffer a DMA may be writing.
@@ -606,62 +605,73 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
     stage(std::integral_constant<int, 2>{});
     stage(std::integral_constant<int, 3>{});
     advance();
-    stage(std::integral_constant<int, 0>{});
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // A-h0, B-h0, B-h1 of K-tile 0 are in; A-h1 may still fly
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (wm == 1) __builtin_amdgcn_s_barrier();        // waves 4..7 run one barrier behind
+    if (wm == 1) __builtin_amdgcn_s_barrier();        // waves 4..7 run one barrier behind (without the skew: 20 % slower)
     __builtin_amdgcn_sched_barrier(0);
 
-    // One phase: fragment reads of the operands it introduces (RA: A half X, RB: B half Y), the two DMA instructions of
-    // half-tile J, the wait that retires the half-tile first read in the NEXT phase, barrier, 16 MFMAs on quadrant (X, Y),
-    // barrier.  In-kernel stamps (-DP8_STAMPS) put a phase at ~1150 cycles: fragment reads 100, the two DMAs 350, the wait
-    // for DMA data 10, barriers 85 + 260, MFMA issue 320 -- the kernel is bound by the ISSUE cost of the LDS-DMA
-    // instructions (1 KiB each, ~175 cycles), not by their latency.  Moving the DMAs between or behind the MFMAs, splitting
-    // them over both segments, a deeper prefetch, XCD-contiguous placement and dropping s_setprio all measured neutral to
-    // 20 % slower (profiles/r02_notes.md).
-    auto phase = [&](auto XC, auto YC, auto RAC, auto RBC, auto JC, auto ADVC, const unsigned char *buf) {
-        constexpr int X = decltype(XC)::value, Y = decltype(YC)::value;
-        constexpr bool RA = decltype(RAC)::value, RB = decltype(RBC)::value, ADV = decltype(ADVC)::value;
-        f16x8 (&bf)[2][2] = *(Y ? &bf1 : &bf0);
-        P8_STAMP(5);                                   // second-barrier wait of the previous phase
-        if (RB) {
+    // One phase = one A half of the K-tile against both B halves: 32 MFMAs between two barriers (r2 first had four phases
+    // of 16 MFMAs per K-tile; halving the barrier round trips per MFMA was worth 5-12 % on the 3x3 layers, while a third
+    // fewer LDS-DMA instructions -- a timing ablation -- was worth nothing: profiles/r02_notes.md).
+    //   X = 0: fragments of A-h0, B-h0, B-h1 (16 ds_read_b128); DMA of A-h0, B-h0, B-h1 of the NEXT K-tile, whose slots were
+    //          last read two phases ago; vmcnt(6) retires A-h1 of this K-tile (issued one phase ago); quadrants (A0,B0) (A0,B1)
+    //   X = 1: fragments of A-h1 (8); DMA of A-h1 of the next K-tile, cursor advance; vmcnt(2) retires the six DMAs of the
+    //          X = 0 phase, i.e. everything the next phase reads; quadrants (A1,B1) (A1,B0) with the B fragments still in registers
+    // Stamps (-DP8_STAMPS): [0] fragment reads issued, [1] DMA issue, [2] wait for DMA data, [3] first barrier, [4] matrix
+    // segment, [5] second barrier, [6] epilogue.
+    auto phase = [&](auto XC, const unsigned char *buf) {
+        constexpr int X = decltype(XC)::value;
+        P8_STAMP(5);
+        if (X == 0) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bf[j][0] = *(const f16x8 *)(buf + b_base + Y * HALF_B + j * 2048 + fo0);
-                bf[j][1] = *(const f16x8 *)(buf + b_base + Y * HALF_B + j * 2048 + fo1);
+                bf0[j][0] = *(const f16x8 *)(buf + b_base + 0 * HALF_B + j * 2048 + fo0);
+                bf0[j][1] = *(const f16x8 *)(buf + b_base + 0 * HALF_B + j * 2048 + fo1);
+                bf1[j][0] = *(const f16x8 *)(buf + b_base + 1 * HALF_B + j * 2048 + fo0);
+                bf1[j][1] = *(const f16x8 *)(buf + b_base + 1 * HALF_B + j * 2048 + fo1);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (RA) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i][0] = *(const f16x8 *)(buf + X * HALF_B + a_base + i * 2048 + fo0);
-                af[i][1] = *(const f16x8 *)(buf + X * HALF_B + a_base + i * 2048 + fo1);
-            }
-        }
-        P8_STAMP(0);                                   // fragment reads issued (and, with the stamp, returned)
-        stage(JC);
-        if (ADV) advance();
-        P8_STAMP(1);                                   // DMA issue
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        P8_STAMP(2);                                   // wait for the half-tile staged three phases ago
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        if (RA || RB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        P8_STAMP(3);                                   // first-barrier wait
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const f16x8 *)(buf + X * HALF_B + a_base + i * 2048 + fo0);
+            af[i][1] = *(const f16x8 *)(buf + X * HALF_B + a_base + i * 2048 + fo1);
+        }
+        P8_STAMP(0);
+        if (X == 0) {
+            stage(std::integral_constant<int, 0>{});
+            stage(std::integral_constant<int, 1>{});
+            stage(std::integral_constant<int, 2>{});
+            P8_STAMP(1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            stage(std::integral_constant<int, 3>{});
+            advance();
+            P8_STAMP(1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        P8_STAMP(2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P8_STAMP(3);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        // first the B half whose fragments are older: (A0,B0) (A0,B1) / (A1,B1) (A1,B0)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+        for (int yy = 0; yy < 2; ++yy) {
+            const int Y = X ? 1 - yy : yy;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[X][Y][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], bf[j][kk], acc[X][Y][i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[X][Y][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][kk], Y ? bf1[j][kk] : bf0[j][kk], acc[X][Y][i][j], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        P8_STAMP(4);                                   // matrix segment (issue of 16 MFMAs)
+        P8_STAMP(4);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -694,10 +704,8 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned char *buf = p8_smem + cbuf * BUF_B;
             // quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0); half-tile staged: the one first read D half-tiles later
-            phase(I0{}, I0{}, T_{}, T_{}, I1{}, F_{}, buf);
-            phase(I0{}, I1{}, F_{}, T_{}, I2{}, F_{}, buf);
-            phase(I1{}, I1{}, T_{}, F_{}, I3{}, T_{}, buf);
-            phase(I1{}, I0{}, F_{}, F_{}, I0{}, F_{}, buf);
+            phase(I0{}, buf);
+            phase(I1{}, buf);
             cbuf ^= 1;
         }
 
