@@ -155,6 +155,15 @@ int y2h_conv_uses_mfma(const y2h_conv *d);
 /* bytes of split-K scratch y2h_conv_forward needs for this descriptor (0 = none): small grids
  * (13x13 maps at small batch, batch-1 inference) are cut along K so that all 256 CUs get work */
 size_t y2h_conv_workspace_bytes(const y2h_conv *d);
+/* Stream-K plan of the fp16 256x256 persistent kernel (replaces nothing in the reference: its GEMM is one cuBLAS call per
+ * image, convolutional_kernels.cu:108-116): of `ntiles` output tiles of `nk` K-tiles each on a persistent grid of `grid`
+ * workgroups, the last *sk_tiles are cut along K into equal shares for workgroups 0 .. *sk_wgs - 1 and finished by a
+ * fix-up launch.  Returns 1 when the plan splits, 0 when every tile is walked whole.  Host arithmetic only (no GPU). */
+int y2h_p8_stream_k_plan(long ntiles, int nk, long grid, int *sk_tiles, int *sk_wgs);
+/* number of stream-K launches (main + fix-up pairs) issued by this process so far (tests, benchmark reports) */
+unsigned long y2h_stream_k_launches(void);
+/* number of small-tile tail launches behind the fp16 256x256 kernel (the other way to finish a partial last round) */
+unsigned long y2h_tail_launches(void);
 /* 1 when the shape fits the dedicated first-layer kernel (3 channels, 3x3/1 pad 1, <= 64
  * filters) provided the input is supplied with a halo (x_halo = 1) */
 int y2h_conv_first_layer_ok(const y2h_conv *d);

@@ -1086,6 +1086,7 @@ extern "C" int y2h_conv_candidates(const y2h_conv *d, int *bm, int *bn, int *ks,
 extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)
 {
     int ksplit = 1;
+    if (d->x_f16 && !d->x_halo) return y2_f16_conv_workspace_bytes(d);      // stream-K piece slots of the fp16 256x256 kernel
     if (d->x_halo || d->x_f16 || !mfma_ok(d) || !pick_variant(d, &ksplit) || ksplit <= 1) return 0;
     return (size_t)ksplit * d->batch * d->out_h * d->out_w * d->n * sizeof(float);
 }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
         const bool live = tile < a.ntiles;
         c0 = 0;
         tap = 0;
-        const int p0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+        const int p0 = a.row0 + (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
         // Row geometry with ONE coordinate decode per thread and tile: this thread's rows are RP apart, so the
         // image coordinates of the following rows come from a carry update.  (With a matrix pipe this fast the
         // per-row divisions and nine tap tests of the fp32 kernel's setup were ~10 % of a tile.)  Unit grid:
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void conv_mfma_f16_kernel(ConvK 
     for (int cti = 0;; ++cti) {
         const int ct = tile_at(cti);
         if (ct >= a.ntiles) break;
-        const int p0 = (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
+        const int p0 = a.row0 + (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
         if constexpr (M16) {
 #pragma unroll
             for (int i = 0; i < TM6; ++i)
@@ -485,6 +485,103 @@ typedef __attribute__((address_space(3))) void lds_void;
 #define P8_STAMP(k) do { } while (0)
 #endif
 
+// One quadrant (A half x, B half y) of a wave's 128 x 64 share of a 256x256 tile: four 16-row tiles x two 16-filter tiles,
+// lane (l16, lq) holds filter l16 and GEMM rows 4 lq .. 4 lq + 3 of each (with the fused pool: one pooling window).
+// Folded batch-norm + activation, optional 2x2 maxpool, half outputs as 16-byte stores through the wave-private LDS
+// scratch `es` (LDS operations of one wave execute in order: no barrier).  pq = first GEMM row, cb = first filter.
+// Shared by conv_p8_f16_kernel and the stream-K fix-up kernel, so a fixed-up tile takes the same arithmetic.
+__device__ __forceinline__ void p8_epilogue_quadrant(const ConvK &a, const int ACT_, const f32x4 (&q)[4][2], const int pq, const int cb,
+                                                     const float al0, const float be0, const float al1, const float be1,
+                                                     _Float16 *es, const int lane)
+{
+    constexpr int ES = 40;
+    _Float16 *yh = (_Float16 *)a.y;
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
+    if (a.pool) {
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {            // two 16-row tiles = 8 pooled rows
+            const int pb = pq + ip * 32;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const f32x4 q0 = q[2 * ip + ti][0], q1 = q[2 * ip + ti][1];
+                float m0 = epilogue_fast(q0[0], al0, be0, ACT_), m1 = epilogue_fast(q1[0], al1, be1, ACT_);
+#pragma unroll
+                for (int u = 1; u < 4; ++u) {
+                    m0 = __builtin_fmaxf(m0, epilogue_fast(q0[u], al0, be0, ACT_));
+                    m1 = __builtin_fmaxf(m1, epilogue_fast(q1[u], al1, be1, ACT_));
+                }
+                es[(ti * 4 + lq) * ES + l16] = (_Float16)m0;
+                es[(ti * 4 + lq) * ES + 16 + l16] = (_Float16)m1;
+            }
+            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+            const int prow = (pb >> 2) + rrow;
+            if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pb = pq + i * 16;
+            const f32x4 q0 = q[i][0], q1 = q[i][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                es[(lq * 4 + r) * ES + l16] = (_Float16)epilogue_fast(q0[r], al0, be0, ACT_);
+                es[(lq * 4 + r) * ES + 16 + l16] = (_Float16)epilogue_fast(q1[r], al1, be1, ACT_);
+            }
+            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
+            const int p = pb + rrow;
+            if (p < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
+        }
+    }
+}
+
+// Stream-K share of workgroup w: K-tile iterations [w * I / G, (w + 1) * I / G) of the I = sk_tiles * nk iterations of the
+// tail tiles (the kernel and the fix-up launch must agree on this arithmetic)
+__device__ __host__ static inline long sk_share_begin(long w, long I, long G) { return w * I / G; }
+
+// Second launch of a stream-K convolution: block (tail tile ts, wave wv of the producing workgroups), its four waves take
+// the four quadrants of that wave's share.  A piece slot holds the accumulators as the producing thread held them:
+// [slot][e = ((x*2+y)*4+i)*2+j][thread 0..511] f32x4, so both sides move whole 1 KB lines.  Pieces are added in ascending
+// K order (= ascending workgroup number), a fixed order: results are reproducible run to run.
+__global__ __launch_bounds__(256) void conv_p8_fixup_kernel(ConvK a, int nk)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 es_all[4 * 32 * 40];
+    const int ts = blockIdx.x >> 3, wv = blockIdx.x & 7;
+    const int qd = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = qd >> 1, y = qd & 1, wm = wv >> 2, wn = wv & 3;
+    const long I = (long)a.sk_tiles * nk, G = a.sk_wgs;
+    const long tb = (long)ts * nk, te = tb + nk;
+    long w = tb * G / I;
+    while (w > 0 && sk_share_begin(w, I, G) > tb) --w;
+    while (w + 1 < G && sk_share_begin(w + 1, I, G) <= tb) ++w;        // first share that reaches into this tile
+    f32x4 q[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) q[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (; w < G; ++w) {
+        const long lo = sk_share_begin(w, I, G), hi = sk_share_begin(w + 1, I, G);
+        if (lo >= te) break;
+        if (hi <= lo) continue;
+        const int slot = 2 * (int)w + (lo < tb ? 1 : 0);       // a share that began in the previous tile: its second piece
+        const f32x4 *src = (const f32x4 *)a.ws + ((size_t)slot * 32 + (size_t)(x * 2 + y) * 8) * 512 + wv * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 v = src[(size_t)(i * 2 + j) * 512];
+                q[i][j] = q[i][j] + v;
+            }
+    }
+    const int tile = a.ntiles - a.sk_tiles + ts;
+    const int p0 = (tile / a.tiles_n) * 256, n0 = (tile % a.tiles_n) * 256;
+    const int cb = n0 + y * 128 + wn * 32, l16 = lane & 15;
+    const int c0f = cb + l16, c1f = cb + 16 + l16;
+    const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
+    const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
+    p8_epilogue_quadrant(a, a.act, q, p0 + x * 128 + wm * 64, cb, al0, be0, al1, be1, es_all + qd * 32 * 40, lane);
+}
+
 template <int KS>
 __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
 {
@@ -518,9 +615,26 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
         const int nwg = gridDim.x, xcd = wgid & 7, q = nwg >> 3, r = nwg & 7;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wgid >> 3);
     }
-    auto tile_at = [&](int i) -> int {
-        const long tl = (long)wgid + (long)i * gridDim.x;
-        return tl < a.ntiles ? (int)tl : a.ntiles;
+    // Work items of this workgroup: first its stream-K share of the tail tiles (0, 1 or 2 pieces = (tile, K range), raw sums
+    // to piece slot 2*wg + piece), then whole tiles wg, wg + G, ... of the first ntiles - sk_tiles.  The pieces come FIRST, so
+    // their 256 KB stores drain under the whole tiles that follow and every workgroup ends on a full-tile epilogue.
+    const int ndp = a.ntiles - a.sk_tiles;
+    int n_sk = 0, sk_t0 = 0, sk_kb0 = 0, sk_ke0 = 0, sk_ke1 = 0;
+    if (a.sk_tiles > 0 && wgid < a.sk_wgs) {
+        const long I = (long)a.sk_tiles * nk;
+        const long lo = sk_share_begin(wgid, I, a.sk_wgs), hi = sk_share_begin(wgid + 1, I, a.sk_wgs);
+        if (hi > lo) {
+            const int t0 = (int)(lo / nk), k0 = (int)(lo - (long)t0 * nk), len = (int)(hi - lo);      // len <= nk: sk_tiles <= sk_wgs
+            sk_t0 = ndp + t0; sk_kb0 = k0; sk_ke0 = k0 + len < nk ? k0 + len : nk; n_sk = 1;
+            if (k0 + len > nk) { sk_ke1 = k0 + len - nk; n_sk = 2; }
+        }
+    }
+    struct Item { int tile, kb, ke, slot; };
+    auto item_at = [&](int i) -> Item {
+        if (i < n_sk) return i == 0 ? Item{sk_t0, sk_kb0, sk_ke0, 2 * wgid} : Item{sk_t0 + 1, 0, sk_ke1, 2 * wgid + 1};
+        const long tl = (long)wgid + (long)(i - n_sk) * gridDim.x;
+        if (tl < ndp) return Item{(int)tl, 0, nk, -1};
+        return Item{a.ntiles, 0, 0x40000000, -1};               // past the end: everything masked, never hop again
     };
     auto setup_tile = [&](int tile) {
         const bool live = tile < a.ntiles;
@@ -554,9 +668,15 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
             b_off[q] = (live && co < (unsigned)a.Cout) ? co * (unsigned)a.K * 2u + scs : a.wbytes;
         }
     };
-    // cursor of the staging side: K-tile (s_tap, s_c0) of tile s_lti, in LDS buffer s_buf
-    int s_tap = 0, s_c0 = 0, s_kt = 0, s_lti = 0, s_buf = 0;
-    setup_tile(tile_at(0));
+    // cursor of the staging side: K-tile (s_tap, s_c0) of work item s_lti (s_rem K-tiles of it still to stage), in LDS buffer s_buf
+    int s_tap = 0, s_c0 = 0, s_rem = 0, s_lti = 0, s_buf = 0;
+    auto begin_item = [&](const Item &it) {
+        setup_tile(it.tile);
+        s_c0 = (it.kb / (KS * KS)) * BK;
+        s_tap = it.kb % (KS * KS);
+        s_rem = it.ke - it.kb;
+    };
+    begin_item(item_at(0));
     // one half-tile = two DMA instructions per thread (U = 0, 1): J = 0 A-h0, 1 B-h0, 2 B-h1, 3 A-h1
     auto stage_one = [&](auto JC, auto UC) {
         constexpr int J = decltype(JC)::value, U = decltype(UC)::value;
@@ -584,10 +704,10 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
         stage_one(JC, std::integral_constant<int, 0>{});
         stage_one(JC, std::integral_constant<int, 1>{});
     };
-    auto advance = [&]() {        // the cursor moves to the next K-tile (of the next tile after the last one)
+    auto advance = [&]() {        // the cursor moves to the next K-tile (of the next work item after the last one)
         s_buf ^= 1;
         if (++s_tap == KS * KS) { s_tap = 0; s_c0 += BK; }
-        if (++s_kt == nk) { s_kt = 0; s_tap = 0; s_c0 = 0; setup_tile(tile_at(++s_lti)); }
+        if (--s_rem == 0) begin_item(item_at(++s_lti));
     };
 
     // ---- matrix side: fragment addresses.  Lane (l16, lq) of a 16x16x32 operand holds k = 32 kk + 8 lq .. +7 of row l16 ----
@@ -685,10 +805,12 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
 
 #ifdef P8_STAMPS
     st_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz: in-kernel clock = cycles / (ticks * 10 ns)
 #endif
     int cbuf = 0;
     for (int cti = 0;; ++cti) {
-        const int ct = tile_at(cti);
+        const Item it = item_at(cti);
+        const int ct = it.tile;
         if (ct >= a.ntiles) break;
         const int p0 = (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
 #pragma unroll
@@ -701,7 +823,7 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[x][y][i][j][r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = it.kb; kt < it.ke; ++kt) {
             const unsigned char *buf = p8_smem + cbuf * BUF_B;
             // quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0); half-tile staged: the one first read D half-tiles later
             phase(I0{}, buf);
@@ -709,12 +831,24 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
             cbuf ^= 1;
         }
 
+        // ---- stream-K piece: the raw sums leave as they stand, 32 coalesced 16-byte stores per lane (see conv_p8_fixup_kernel) ----
+        if (it.slot >= 0) {
+            f32x4 *wsp = (f32x4 *)a.ws + (size_t)it.slot * (32 * 512) + t;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) wsp[(size_t)((((x * 2 + y) * 4 + i) * 2 + j)) * 512] = acc[x][y][i][j];
+            P8_STAMP(6);
+            continue;
+        }
         // ---- epilogue (no barrier inside: the wave groups keep their one-barrier skew across tiles) ----
         auto epilogue_pass = [&](auto LEAKYC) {
             const int ACT_ = decltype(LEAKYC)::value ? (int)Y2H_ACT_LEAKY : a.act;
-            _Float16 *yh = (_Float16 *)a.y;
             _Float16 *es = (_Float16 *)(p8_smem + 2 * BUF_B) + wv * 32 * ES;
-            const int rrow = lane >> 2, rchunk = (lane & 3) * 8;
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
                 const int cb = n0 + y * 128 + wn * 32;             // 32 filters: two 16-wide MFMA tiles
@@ -722,43 +856,8 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
                 const float al0 = c0f < a.Cout ? a.alpha[c0f] : 0.f, be0 = c0f < a.Cout ? a.beta[c0f] : 0.f;
                 const float al1 = c1f < a.Cout ? a.alpha[c1f] : 0.f, be1 = c1f < a.Cout ? a.beta[c1f] : 0.f;
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    if (a.pool) {
-#pragma unroll
-                        for (int ip = 0; ip < 2; ++ip) {            // two 16-row tiles = 8 pooled rows
-                            const int pb = p0 + x * 128 + wm * 64 + ip * 32;
-#pragma unroll
-                            for (int ti = 0; ti < 2; ++ti) {
-                                const f32x4 q0 = acc[x][y][2 * ip + ti][0], q1 = acc[x][y][2 * ip + ti][1];
-                                float m0 = epilogue_fast(q0[0], al0, be0, ACT_), m1 = epilogue_fast(q1[0], al1, be1, ACT_);
-#pragma unroll
-                                for (int u = 1; u < 4; ++u) {
-                                    m0 = __builtin_fmaxf(m0, epilogue_fast(q0[u], al0, be0, ACT_));
-                                    m1 = __builtin_fmaxf(m1, epilogue_fast(q1[u], al1, be1, ACT_));
-                                }
-                                es[(ti * 4 + lq) * ES + l16] = (_Float16)m0;
-                                es[(ti * 4 + lq) * ES + 16 + l16] = (_Float16)m1;
-                            }
-                            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
-                            const int prow = (pb >> 2) + rrow;
-                            if (lane < 32 && 4 * prow < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)prow * a.ldy + cb + rchunk] = v;
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int pb = p0 + x * 128 + wm * 64 + i * 16;
-                            const f32x4 q0 = acc[x][y][i][0], q1 = acc[x][y][i][1];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                es[(lq * 4 + r) * ES + l16] = (_Float16)epilogue_fast(q0[r], al0, be0, ACT_);
-                                es[(lq * 4 + r) * ES + 16 + l16] = (_Float16)epilogue_fast(q1[r], al1, be1, ACT_);
-                            }
-                            const f32x4 v = *(const f32x4 *)&es[rrow * ES + rchunk];
-                            const int p = pb + rrow;
-                            if (p < a.npix && cb + rchunk < a.Cout) *(f32x4 *)&yh[(size_t)p * a.ldy + cb + rchunk] = v;
-                        }
-                    }
-                }
+                for (int x = 0; x < 2; ++x)
+                    p8_epilogue_quadrant(a, ACT_, acc[x][y], p0 + x * 128 + wm * 64, cb, al0, be0, al1, be1, es, lane);
             }
         };
         if (a.act == Y2H_ACT_LEAKY) epilogue_pass(std::true_type{});
@@ -766,8 +865,9 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
         P8_STAMP(6);                                       // epilogue
     }
 #ifdef P8_STAMPS
-    if (lane == 0 && a.ws)
-        for (int k = 0; k < 8; ++k) ((unsigned long long *)a.ws)[((size_t)blockIdx.x * 8 + wv) * 8 + k] = st_acc[k];
+    st_acc[7] = __builtin_amdgcn_s_memrealtime() - st_real0;
+    if (lane == 0 && a.stamps)
+        for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * 8 + wv) * 8 + k] = st_acc[k];
 #endif
     __builtin_amdgcn_sched_barrier(0);
     if (wm == 0) __builtin_amdgcn_s_barrier();        // pairs with the extra barrier waves 4..7 took at the start
@@ -1072,6 +1172,141 @@ static VariantH *pick_h(const y2h_conv *d)
     return best;
 }
 
+// ---------------------------------------------------------------------------
+// Stream-K plan of the 256x256 LDS-DMA kernel.  A persistent grid of G workgroups walks ntiles tiles in ceil(ntiles / G)
+// rounds; the last round holds only R = ntiles mod G tiles (darknet19_448 b128: 392 / 784 / 1568 tiles on 256 CUs = 77 / 77 /
+// 88 % occupancy).  With stream-K the R tail tiles are cut along K into equal shares for `wgs` workgroups (pieces of >= MINK
+// K-tiles), at the price of the piece traffic (256 KB per piece, written once and read once) and a second launch.
+// Estimated in units of one K-tile of one workgroup (~1.7 us): a tile costs nk + C_TILE, a piece its K-tiles + C_TILE,
+// the fix-up launch FIX_LAUNCH + pieces * FIX_PIECE.  Env: Y2_SK=0 off, Y2_SK_TILES / Y2_SK_WGS force (tests, sweeps).
+// ---------------------------------------------------------------------------
+static unsigned long g_sk_launches = 0;
+extern "C" unsigned long y2h_stream_k_launches(void) { return g_sk_launches; }
+
+extern "C" int y2h_p8_stream_k_plan(long ntiles, int nk, long grid, int *sk_tiles, int *sk_wgs)
+{
+    *sk_tiles = 0; *sk_wgs = 0;
+    if (ntiles <= 0 || nk <= 0 || grid <= 1) return 0;
+    const char *on = getenv("Y2_SK");
+    if (on && atoi(on) == 0) return 0;
+    const char *ft = getenv("Y2_SK_TILES"), *fw = getenv("Y2_SK_WGS");
+    if (ft && atol(ft) > 0) {
+        long t = atol(ft), w = fw && atol(fw) > 0 ? atol(fw) : grid;
+        if (t > ntiles) t = ntiles;
+        if (w > grid) w = grid;
+        if (w < t) w = t;                                   // a share never exceeds one tile
+        if (w > grid) return 0;
+        *sk_tiles = (int)t; *sk_wgs = (int)w;
+        return 1;
+    }
+    const long R = ntiles % grid;
+    if (R == 0) return 0;
+    const double C_TILE = 5.0, FIX_LAUNCH = 3.0, FIX_PIECE = 0.04;
+    int MINK = 4;
+    double margin = 0.97;                                   // sweeps: Y2_SK_MARGIN=2 splits whenever a split is possible
+    if (const char *m = getenv("Y2_SK_MARGIN")) margin = atof(m);
+    if (const char *m = getenv("Y2_SK_MINK")) { if (atoi(m) > 0) MINK = atoi(m); }
+    const long rounds = ntiles / grid;
+    const double t_plain = (double)(rounds + 1) * (nk + C_TILE);
+    long wgs = (R * nk) / MINK;
+    if (wgs > grid) wgs = grid;
+    if (wgs <= R) return 0;                                 // shares of a whole tile or more: nothing to gain
+    const double share = (double)R * nk / wgs;
+    const double pieces = (double)wgs + (double)R;          // every share is one piece, plus one more per tile boundary it crosses
+    const double t_sk = (double)rounds * (nk + C_TILE) + share + C_TILE * (1.0 + (double)R / wgs) + FIX_LAUNCH + pieces * FIX_PIECE;
+    if (t_sk >= margin * t_plain) return 0;
+    *sk_tiles = (int)R; *sk_wgs = (int)wgs;
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
+// The other way to finish a partial last round: a second launch that covers the tail tiles' GEMM rows with a SMALLER tile
+// of the register-staged kernel (ConvK.row0), so that the rows spread over all 256 CUs again.  No partial sums, no
+// workspace: worth it when the tail is a small part of a round (784 tiles = 3 rounds + 16 tiles: those 4096 rows x 512
+// filters are 256 tiles of 64x64... one per CU) -- stream-K moves 256 KB per piece and pays a burst of piece stores.  A
+// small tile runs at a fraction of the 256x256 kernel's efficiency (REL, measured: profiles/r03_notes.md), so a tail of
+// half a round or more is better off with stream-K or as it is.
+// Tile numbers are filter-tile fastest, and the whole-tile part is a multiple of the grid (256) and therefore of tiles_n
+// (1, 2 or 4): the tail is the row range [row0, npix) x all filters.
+// Env: Y2_TAIL=0 off; Y2_TAIL_TILE=BMxBN forces the tail tile (and the tail itself whenever there is a partial round),
+// Y2_TAIL_TILES=n the number of 256x256 tiles handed to it (tests).
+// ---------------------------------------------------------------------------
+static VariantH *find_h(int bm, int bn, int bk, int ks, bool vec_ok)
+{
+    for (VariantH &v : g_variants_h)
+        if (!v.p8 && v.bm == bm && v.bn == bn && v.bk == bk && v.ks == ks && (!v.m16 || vec_ok)) return &v;
+    return nullptr;
+}
+
+static unsigned long g_tail_launches = 0;
+extern "C" unsigned long y2h_tail_launches(void) { return g_tail_launches; }
+
+// estimated time of `rows` GEMM rows x n filters on variant v, in units of one K-tile of the 256x256 kernel
+static double tail_cost(const VariantH &v, long rows, int n, int nk)
+{
+    double rel = 0.25;                                      // efficiency relative to the 256x256 LDS-DMA kernel
+    if (v.bm == 256 && v.bn == 128) rel = 0.62;
+    else if (v.bm == 256 && v.bn == 64) rel = 0.45;
+    else if (v.bm == 128 && v.bn == 128) rel = 0.50;
+    else if (v.bm == 128 && v.bn == 64) rel = 0.40;
+    else if (v.bm == 64 && v.bn == 64) rel = 0.30;
+    const long tiles = ((rows + v.bm - 1) / v.bm) * ((n + v.bn - 1) / v.bn);
+    const int bpc = bpc_h(v);
+    long per_cu;
+    if (tiles <= 256L * bpc) per_cu = (tiles + 255) / 256;
+    else per_cu = (long)bpc * ((tiles + 256L * bpc - 1) / (256L * bpc));
+    return 1.5 + (double)per_cu * ((double)v.bm * v.bn / 65536.0) / rel * (nk + 6.0);
+}
+
+struct P8Plan {
+    int sk_tiles, sk_wgs;          // stream-K (0: none)
+    int tail_tiles;                // 256x256 tiles handed to the tail launch (0: none)
+    VariantH *tail;
+};
+
+static P8Plan p8_plan(const y2h_conv *d, long ntiles, int tiles_n, int nk, long grid)
+{
+    P8Plan pl = {0, 0, 0, nullptr};
+    const bool vec_ok = d->y_f16 && d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0;
+    const char *toff = getenv("Y2_TAIL");
+    const bool tail_on = !(toff && atoi(toff) == 0);
+    int fbm = 0, fbn = 0;
+    if (const char *f = getenv("Y2_TAIL_TILE")) sscanf(f, "%dx%d", &fbm, &fbn);
+    const char *ftn = getenv("Y2_TAIL_TILES");
+    const long npix = (long)d->batch * d->h * d->w;
+    if (tail_on && fbm && ((ftn && atol(ftn) > 0) || ntiles % grid)) {          // forced
+        VariantH *tv = find_h(fbm, fbn, 64, d->size, vec_ok);
+        long t = (ftn && atol(ftn) > 0) ? atol(ftn) : ntiles % grid;
+        if (t > ntiles) t = ntiles;
+        while ((ntiles - t) % tiles_n) ++t;                 // the whole-tile part ends on a row boundary
+        if (tv && t <= ntiles) { pl.tail_tiles = (int)t; pl.tail = tv; return pl; }
+    }
+    if (y2h_p8_stream_k_plan(ntiles, nk, grid, &pl.sk_tiles, &pl.sk_wgs) && (getenv("Y2_SK_TILES") || !tail_on)) return pl;
+    const long R = ntiles % grid;
+    if (R == 0 || !tail_on || (ntiles - R) % tiles_n) return pl;
+    // three candidates for the last round: as it is, stream-K (estimate inside y2h_p8_stream_k_plan, recomputed here), tail
+    const double C_TILE = 5.0;
+    const double t_round = nk + C_TILE;
+    double t_sk = 1e30;
+    if (pl.sk_tiles) {
+        const double share = (double)R * nk / pl.sk_wgs, pieces = (double)pl.sk_wgs + (double)R;
+        t_sk = share + C_TILE * (1.0 + (double)R / pl.sk_wgs) + 3.0 + pieces * 0.04;
+    }
+    const long rows = npix - ((ntiles - R) / tiles_n) * 256;
+    VariantH *best = nullptr;
+    double t_tail = 1e30;
+    for (VariantH &tv : g_variants_h) {
+        if (tv.p8 || tv.bk != 64 || tv.ks != d->size || (tv.m16 && !vec_ok) || (tv.bm == 256 && tv.bn == 256)) continue;
+        const double c = tail_cost(tv, rows, d->n, nk);
+        if (c < t_tail) { t_tail = c; best = &tv; }
+    }
+    if (best && t_tail < 0.97 * t_round && t_tail < t_sk) { pl.sk_tiles = pl.sk_wgs = 0; pl.tail_tiles = (int)R; pl.tail = best; }
+    return pl;
+}
+
+// piece slots the plan may need for this descriptor (bytes of y2h_conv.ws)
+size_t y2_f16_conv_workspace_bytes(const y2h_conv *d);
+
 const char *y2_f16_conv_variant(const y2h_conv *d)
 {
     if (c32_ok(d)) return "conv_c32_f16_16x16";
@@ -1104,41 +1339,94 @@ int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     if (v->p8 && getenv("Y2_P8_REMAP")) a.dbg |= 64;            // A/B: XCD-contiguous placement of workgroups
     long grid = 256L * bpc_h(*v);
     if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }   // tests: many tiles per workgroup on small shapes
-    if (grid > a.ntiles) grid = a.ntiles;
+    bool sk = false;
+    ConvK tl;                       // the tail launch, if the plan has one
+    VariantH *tailv = nullptr;
+    if (v->p8) {
+        const P8Plan pl = p8_plan(d, a.ntiles, a.tiles_n, d->size * d->size * (d->c / 64), grid);
+        if (pl.sk_tiles && d->ws && d->ws_bytes >= (size_t)2 * pl.sk_wgs * 256 * 256 * sizeof(float)) {
+            a.sk_tiles = pl.sk_tiles; a.sk_wgs = pl.sk_wgs; a.ws = d->ws;
+            sk = true;
+        } else if (pl.tail_tiles) {
+            tailv = pl.tail;
+            tl = a;
+            a.ntiles -= pl.tail_tiles;
+            tl.row0 = (a.ntiles / a.tiles_n) * 256;
+            tl.tiles_n = (d->n + tailv->bn - 1) / tailv->bn;
+            tl.ntiles = (int)((((long)a.npix - tl.row0 + tailv->bm - 1) / tailv->bm) * tl.tiles_n);
+        }
+    }
+    if (!sk && grid > a.ntiles) grid = a.ntiles;
+    if (sk) {            // whole tiles need min(grid, ntiles - sk_tiles) workgroups, the shares sk_wgs
+        long need = a.ntiles - a.sk_tiles;
+        if (need < a.sk_wgs) need = a.sk_wgs;
+        if (grid > need) grid = need;
+    }
 #ifdef P8_STAMPS
     static unsigned long long *d_st = nullptr;
     if (v->p8) {
         if (!d_st) Y2H_CHECK(hipMalloc((void **)&d_st, 256 * 8 * 8 * sizeof(unsigned long long)));
         Y2H_CHECK(hipMemsetAsync(d_st, 0, 256 * 8 * 8 * sizeof(unsigned long long), S(s)));
-        a.ws = (float *)d_st;
+        a.stamps = d_st;
     }
 #endif
-    hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
-    Y2H_LAUNCH_CHECK();
+    if (grid > 0) {
+        hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
+        Y2H_LAUNCH_CHECK();
+    }
+    if (tailv) {
+        if (dev < 0 || dev >= 16 || !tailv->attr_set[dev]) {
+            Y2H_CHECK(hipFuncSetAttribute((const void *)tailv->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tailv->lds));
+            if (dev >= 0 && dev < 16) tailv->attr_set[dev] = true;
+        }
+        long g2 = 256L * bpc_h(*tailv);
+        if (g2 > tl.ntiles) g2 = tl.ntiles;
+        hipLaunchKernelGGL(tailv->fn, dim3((unsigned)g2), dim3(tailv->threads), tailv->lds, S(s), tl);
+        Y2H_LAUNCH_CHECK();
+        ++g_tail_launches;
+    }
+    if (sk) {
+        hipLaunchKernelGGL(conv_p8_fixup_kernel, dim3((unsigned)a.sk_tiles * 8), dim3(256), 0, S(s), a, d->size * d->size * (d->c / 64));
+        Y2H_LAUNCH_CHECK();
+        ++g_sk_launches;
+    }
 #ifdef P8_STAMPS
     if (v->p8 && getenv("Y2_P8_STAMPS")) {
         static unsigned long long h[256 * 8 * 8];
         Y2H_CHECK(hipStreamSynchronize(S(s)));
         Y2H_CHECK(hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost));
-        const char *names[8] = {"frag reads", "dma issue", "vmcnt wait", "barrier1", "mfma issue", "barrier2", "epilogue", "dma2"};
+        const char *names[8] = {"frag reads", "dma issue", "vmcnt wait", "barrier1", "mfma issue", "barrier2", "epilogue", "(realtime)"};
         const int nk = d->size * d->size * (d->c / 64);
         for (int g = 0; g < 2; ++g) {
             double tot[8] = {0}, phases = 0;
             for (long b = 0; b < grid; ++b) {
                 const long tiles_b = (a.ntiles - b + grid - 1) / grid;
                 for (int w = 4 * g; w < 4 * g + 4; ++w) {
-                    phases += 4.0 * nk * tiles_b;
+                    phases += 2.0 * nk * tiles_b;
                     for (int k = 0; k < 8; ++k) tot[k] += (double)h[(b * 8 + w) * 8 + k];
                 }
             }
             fprintf(stderr, "p8 stamps %dx%d c%d n%d waves %d-%d (shader cycles per phase):", d->h, d->w, d->c, d->n, 4 * g, 4 * g + 3);
             double sum = 0;
-            for (int k = 0; k < 8; ++k) { fprintf(stderr, " %s %.0f", names[k], tot[k] / phases); sum += tot[k]; }
-            fprintf(stderr, " | total %.0f\n", sum / phases);
+            for (int k = 0; k < 7; ++k) { fprintf(stderr, " %s %.0f", names[k], tot[k] / phases); sum += tot[k]; }
+            fprintf(stderr, " | total %.0f | in-kernel clock %.3f GHz (cycles / 100 MHz ticks)\n", sum / phases, tot[7] > 0 ? sum / tot[7] * 0.1 : 0.0);
         }
     }
 #endif
     return Y2H_OK;
+}
+
+size_t y2_f16_conv_workspace_bytes(const y2h_conv *d)
+{
+    if (c32_ok(d) || !y2_f16_conv_ok(d)) return 0;
+    VariantH *v = pick_h(d);
+    if (!v || !v->p8) return 0;
+    const long npix = (long)d->batch * d->h * d->w;
+    const long ntiles = ((npix + 255) / 256) * ((d->n + 255) / 256);
+    long grid = 256L * bpc_h(*v);
+    if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }
+    const P8Plan pl = p8_plan(d, ntiles, (d->n + 255) / 256, d->size * d->size * (d->c / 64), grid);
+    return (size_t)2 * pl.sk_wgs * 256 * 256 * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------

@@ -31,7 +31,13 @@ struct ConvK {
     int tiles_n;
     int ntiles;        // tiles_m * tiles_n * ksplit work items; workgroups walk them with stride gridDim.x
     int ksplit;        // >= 1: number of K ranges each output tile is cut into (split-K)
-    float *ws;         // split-K partial sums [ksplit][npix][Cout]
+    float *ws;         // split-K partial sums [ksplit][npix][Cout]; stream-K: piece slots (see sk_tiles)
+    // Stream-K (persistent kernels): the LAST sk_tiles output tiles are not walked whole.  Their sk_tiles * nk K-tile
+    // iterations are dealt in equal contiguous shares to workgroups 0 .. sk_wgs-1 (share <= one tile: sk_tiles <= sk_wgs),
+    // each share is one or two pieces (tile, K range) whose raw fp32 sums go to slot 2*wg + piece of `ws`, and a fix-up
+    // launch adds a tile's pieces in ascending K order and applies the epilogue.  0 = every tile is walked whole.
+    int sk_tiles, sk_wgs;
+    int row0;          // fp16 matrix-core kernels: first GEMM row of this launch (tail launch behind the 256x256 kernel); tile t starts at row0 + (t / tiles_n) * BM
     unsigned long long *stamps;   // diagnostic builds (-DY2_F32_STAMPS): per-wave cycle counters
     // stride / out_h / out_w: fp32 matrix-core and direct kernels; size / pad / batch: direct kernel only
     int size, stride, pad, out_h, out_w, batch;
@@ -116,6 +122,7 @@ __device__ __forceinline__ int pool_pixel(int r, int H, int W)
 bool y2_f16_conv_ok(const y2h_conv *d);
 const char *y2_f16_conv_variant(const y2h_conv *d);
 int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s);
+size_t y2_f16_conv_workspace_bytes(const y2h_conv *d);
 bool y2_f16_first_ok(const y2h_conv *d);
 int y2_f16_first_launch(const y2h_conv *d, ConvK &a, y2h_stream s);
 bool y2_f16_first_nchw_ok(const y2h_conv *d);

@@ -224,6 +224,9 @@ def lib():
     L.y2h_memcpy_d2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.y2h_stream_sync.argtypes = [C.c_void_p]
     L.y2h_set_device.argtypes = [C.c_int]
+    L.y2h_p8_stream_k_plan.argtypes = [C.c_long, C.c_int, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.y2h_stream_k_launches.restype = C.c_ulong
+    L.y2h_tail_launches.restype = C.c_ulong
     _lib = L
     return L
 

@@ -143,6 +143,75 @@ def test_f16_tile_scalar_store_path_is_exact(oracle, workdir, monkeypatch, tile,
     assert np.array_equal(out, _as_half(ref))
 
 
+# (tail tiles cut along K, workgroups sharing them, persistent grid): 12 output tiles of 256x256 (6 x 2, partial in both
+# dimensions).  5/7/7: one whole tile per workgroup behind its share, shares of 12.9 K-tiles that straddle tile boundaries;
+# 3/3/5: shares of exactly one tile (a tile fixed up from a single piece), two workgroups without a share; 12/13/13: no whole
+# tile at all; 2/7/7 and 7/7/7: more workgroups than K-tiles in the 1x1 cases (empty shares)
+SK_CASES = [(5, 7, 7), (3, 3, 5), (12, 13, 13), (2, 7, 7), (7, 7, 7)]
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("ksize,cin", [(3, 128), (1, 256), (1, 64)], ids=["k3_nk18", "k1_nk4", "k1_nk1"])
+@pytest.mark.parametrize("sk", SK_CASES, ids=lambda c: "sk%d_wg%d_grid%d" % c)
+def test_f16_stream_k_is_exact(oracle, workdir, monkeypatch, sk, ksize, cin, pool):
+    """conv_p8_f16_kernel with stream-K forced (Y2_SK_TILES / Y2_SK_WGS): the tail tiles' K loops are dealt to the
+    workgroups in equal contiguous shares, every share leaves one or two pieces of raw fp32 sums in the workspace and
+    conv_p8_fixup_kernel adds a tile's pieces in K order and applies the epilogue (also the fused 2x2 maxpool).  Integer
+    data: the sums are exact in any order, so the result must EQUAL the oracle's rounded once to half
+    (convolutional_layer.c:435-474, gemm.c:74-88)."""
+    tiles, wgs, grid = sk
+    monkeypatch.setenv("Y2_SK_TILES", str(tiles))
+    monkeypatch.setenv("Y2_SK_WGS", str(wgs))
+    before = darknet.lib().y2h_stream_k_launches()
+    out, ref, name, l0 = _run(oracle, workdir, monkeypatch, cin=cin, filters=256 + 40, ksize=ksize, size=26, batch=2,
+                              tile=(256, 256), pool=pool, half=True, grid=grid,
+                              seed=70000 + tiles * 31 + wgs * 7 + grid + ksize * 100 + cin + pool * 1000)
+    assert name == "conv_mfma_f16_256x256x64_k%d%s" % (ksize, "+maxpool2" if pool else ""), name
+    assert darknet.lib().y2h_stream_k_launches() > before          # the split really ran
+    assert l0 <= 2048 and np.abs(ref).max() < 60000
+    assert np.array_equal(out, _as_half(ref))
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("ksize", [1, 3])
+@pytest.mark.parametrize("ntail", [5, 2, 12], ids=lambda n: "tail%d" % n)
+@pytest.mark.parametrize("tile", [(256, 128), (256, 64), (128, 128), (128, 64), (64, 64)], ids=lambda t: "%dx%d" % t)
+def test_f16_small_tile_tail_is_exact(oracle, workdir, monkeypatch, tile, ntail, ksize, pool):
+    """the other way to finish a partial last round of the 256x256 kernel: the tail tiles' GEMM rows go to a second launch
+    of a smaller register-staged tile (ConvK.row0).  12 tiles of 256x256 (6 x 2): 5 -> 6 tail tiles (the whole-tile part
+    must end on a row boundary: rows 768..1351 x 296 filters), 2 (the last, partial row tile only), 12 (nothing left for
+    the 256x256 kernel).  Exact against the oracle on integer data (convolutional_layer.c:435-474, gemm.c:74-88)."""
+    monkeypatch.setenv("Y2_TAIL_TILES", str(ntail))
+    monkeypatch.setenv("Y2_TAIL_TILE", "%dx%d" % tile)
+    L = darknet.lib()
+    before = L.y2h_tail_launches()
+    out, ref, name, l0 = _run(oracle, workdir, monkeypatch, cin=128, filters=256 + 40, ksize=ksize, size=26, batch=2,
+                              tile=(256, 256), pool=pool, half=True, grid=4,
+                              seed=72000 + tile[0] * 3 + tile[1] + ntail * 17 + ksize * 100 + pool * 1000)
+    assert name == "conv_mfma_f16_256x256x64_k%d%s" % (ksize, "+maxpool2" if pool else ""), name
+    assert L.y2h_tail_launches() > before
+    assert l0 <= 2048 and np.abs(ref).max() < 60000
+    assert np.array_equal(out, _as_half(ref))
+
+
+def test_f16_stream_k_equals_whole_tiles_with_batchnorm_leaky(oracle, workdir, monkeypatch):
+    """the fix-up launch takes the same epilogue code as the kernel's own (p8_epilogue_quadrant): batch-norm + leaky on
+    integer data gives the same bits with and without the split"""
+    outs = []
+    for tiles in (0, 5):
+        if tiles:
+            monkeypatch.setenv("Y2_SK_TILES", str(tiles))
+            monkeypatch.setenv("Y2_SK_WGS", "7")
+        else:
+            monkeypatch.setenv("Y2_SK", "0")
+        out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=128, filters=296, ksize=3, size=26, batch=2, tile=(256, 256),
+                                 pool=True, half=True, grid=7, bn=1, act="leaky", seed=71000)
+        monkeypatch.delenv("Y2_SK", raising=False)
+        outs.append(out.copy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0] - ref).max() <= np.abs(ref).max() * 2.0 ** -9
+
+
 @pytest.mark.parametrize("tile", [(192, 256), (128, 128), (64, 64)], ids=lambda t: "%dx%d" % t)
 @pytest.mark.parametrize("ksplit", [1, 3])
 def test_pooled_epilogue_with_negative_scales(oracle, workdir, monkeypatch, tile, ksplit):

@@ -27,6 +27,8 @@ def main():
     synth.write_weights(wts, zoo.resolve(spec, H), 5)
     net = darknet.Network.parse_network_cfg(cfg)
     net.load_weights(wts)
+    if os.environ.get("Y2_PROBE_HALF"):
+        net.set_half(True)
     x = synth.image_batch(batch, 3, H, H)
     net.network_predict(x)
     net.set_timing(True)
