@@ -56,7 +56,7 @@
 // ---------------------------------------------------------------------------
 // MFMA implicit GEMM
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int BK, int KS, int WM, int WN, bool PIPE>
+template <int BM, int BN, int BK, int KS, int WM, int WN, bool PIPE, bool XO = false>
 __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 {
     constexpr int NT = WM * WN * 64;
@@ -172,6 +172,24 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wgid >> 3);
     }
     auto tile_at = [&](int i) -> int {
+        if constexpr (XO) {        // (a template parameter: as a run-time switch its scalar state costs the 192x256 kernel 88 B more scratch per lane)
+            // work list of XCD x: for each block of pblk pixel tiles, for each of its filter tiles x, x + 8, ..., the block's
+            // pixel tiles; the XCD's gridDim.x / 8 workgroups walk it with that stride
+            const int xcd = wgid & 7, nf = (a.tiles_n - xcd + 7) >> 3;           // filter tiles of this XCD
+            const long idx = (long)(wgid >> 3) + (long)i * (gridDim.x >> 3);
+            if (idx >= (long)nf * a.tiles_m) return a.ntiles;
+            const int full = a.tiles_m / a.pblk, per = nf * a.pblk;               // whole blocks, tiles per whole block
+            int pb, fi, pi;
+            if (idx < (long)full * per) {
+                pb = (int)(idx / per);
+                const int rem = (int)(idx - (long)pb * per);
+                fi = rem / a.pblk; pi = rem - fi * a.pblk;
+            } else {
+                const int last = a.tiles_m - full * a.pblk, rem = (int)(idx - (long)full * per);
+                pb = full; fi = rem / last; pi = rem - fi * last;
+            }
+            return (pb * a.pblk + pi) * a.tiles_n + xcd + 8 * fi;
+        }
         const long tl = (long)wgid + (long)i * gridDim.x;
         return tl < a.ntiles ? (int)tl : a.ntiles;
     };
@@ -926,11 +944,17 @@ struct Variant {
     size_t lds;
     int threads;
     bool attr_set[16];     // per device
+    void (*fn_xo)(ConvK);  // the same tile with the XCD-grouped tile order (ConvK.xcd_order), where instantiated
+    bool attr_set_xo[16];
 };
 
 #define VAR(BM, BN, BK, KS, WM, WN)                                                             \
     { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
-      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false} }
+      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, nullptr, {false} }
+#define VARXO(BM, BN, BK, KS, WM, WN)                                                           \
+    { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
+      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, \
+      conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, true>, {false} }
 
 #ifndef Y2_PIPE
 #define Y2_PIPE true
@@ -938,13 +962,13 @@ struct Variant {
 static Variant g_variants[] = {
     // 8 waves (2 per SIMD), ONE workgroup per CU: the co-resident partner wave that hides LDS/barrier
     // stalls comes from the same workgroup, so a CU never ends up with a lone half-speed pair in the tail
-    VAR(192, 256, 32, 3, 2, 4), VAR(192, 256, 32, 1, 2, 4),
+    VAR(192, 256, 32, 3, 2, 4), VARXO(192, 256, 32, 1, 2, 4),
     VAR(256, 128, 32, 3, 4, 2), VAR(256, 128, 32, 1, 4, 2),
     VAR(256, 64, 32, 3, 8, 1),  VAR(256, 64, 32, 1, 8, 1),
     // 4 waves, two workgroups per CU
-    VAR(128, 128, 32, 3, 2, 2), VAR(128, 128, 32, 1, 2, 2),
+    VAR(128, 128, 32, 3, 2, 2), VARXO(128, 128, 32, 1, 2, 2),
     VAR(128, 64, 32, 3, 2, 2),  VAR(128, 64, 32, 1, 2, 2),
-    VAR(64, 64, 32, 3, 2, 2),   VAR(64, 64, 32, 1, 2, 2),
+    VAR(64, 64, 32, 3, 2, 2),   VARXO(64, 64, 32, 1, 2, 2),
     VAR(128, 32, 32, 3, 4, 1),  VAR(128, 32, 32, 1, 4, 1),
     VAR(128, 128, 16, 3, 2, 2), VAR(128, 128, 16, 1, 2, 2),
     VAR(128, 64, 16, 3, 2, 2),  VAR(128, 64, 16, 1, 2, 2),
@@ -954,6 +978,9 @@ static Variant g_variants[] = {
     VAR(128, 128, 32, 5, 2, 2), VAR(64, 64, 32, 5, 2, 2),
     VAR(128, 128, 16, 5, 2, 2), VAR(64, 64, 16, 5, 2, 2),
 };
+
+static unsigned long g_xcd_order_launches = 0;
+extern "C" unsigned long y2h_xcd_order_launches(void) { return g_xcd_order_launches; }
 
 static bool mfma_ok(const y2h_conv *d)
 {
@@ -1303,13 +1330,41 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         long grid = 256L * variant_bpc(*v);          // persistent: at most what is co-resident
         if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }   // tests: many tiles per workgroup on small shapes
         if (grid > a.ntiles) grid = a.ntiles;
+        {
+            // Wide heads: when the weights are the large operand and there are many filter tiles, filter-tile-fastest numbering
+            // makes every round of workgroups stream the whole weight matrix again (yolo9000 544 b8, final 1x1: 4.3 GB fetched
+            // for 125 MB of operands, profiles/r02_9k544b8_pmc_summary.txt).  See ConvK.xcd_order.  Y2_XCD_ORDER=0/1 forces.
+            const double wb = (double)d->n * a.K * 4.0, xb = (double)a.npix * d->c * 4.0;
+            bool on = v->fn_xo && ksplit == 1 && grid >= 8 && a.tiles_n >= 16 && wb > 2.0 * xb && wb > 16e6;
+            if (const char *f = getenv("Y2_XCD_ORDER")) on = v->fn_xo && atoi(f) != 0 && ksplit == 1 && grid >= 8;
+            if (on) {
+                a.xcd_order = 1;
+                a.tiles_m = (int)tiles_m;
+                const double tile_b = (double)v->bm * d->c * d->size * d->size * 4.0;      // input bytes one pixel tile touches (upper bound)
+                long pb = (long)(3.0e6 / tile_b);
+                if (const char *f = getenv("Y2_XCD_PBLK")) pb = atol(f);
+                if (pb < 1) pb = 1;
+                if (pb > tiles_m) pb = tiles_m;
+                a.pblk = (int)pb;
+                grid -= grid % 8;
+            }
+        }
 #ifdef Y2_F32_STAMPS
         static unsigned long long *d_st = nullptr;
         if (!d_st) Y2H_CHECK(hipMalloc((void **)&d_st, 1024 * 8 * 5 * sizeof(unsigned long long)));
         Y2H_CHECK(hipMemsetAsync(d_st, 0, 1024 * 8 * 5 * sizeof(unsigned long long), S(s)));
         a.stamps = d_st;
 #endif
-        hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
+        if (a.xcd_order) {
+            ++g_xcd_order_launches;
+            if (dev < 0 || dev >= 16 || !v->attr_set_xo[dev]) {
+                Y2H_CHECK(hipFuncSetAttribute((const void *)v->fn_xo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
+                if (dev >= 0 && dev < 16) v->attr_set_xo[dev] = true;
+            }
+            hipLaunchKernelGGL(v->fn_xo, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
+        } else {
+            hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(v->threads), v->lds, S(s), a);
+        }
         Y2H_LAUNCH_CHECK();
 #ifdef Y2_F32_STAMPS
         if (getenv("Y2_F32_STAMPS")) {

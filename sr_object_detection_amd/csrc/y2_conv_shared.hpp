@@ -37,6 +37,11 @@ struct ConvK {
     // each share is one or two pieces (tile, K range) whose raw fp32 sums go to slot 2*wg + piece of `ws`, and a fix-up
     // launch adds a tile's pieces in ascending K order and applies the epilogue.  0 = every tile is walked whole.
     int sk_tiles, sk_wgs;
+    // fp32 matrix-core kernel, wide heads (yolo9000's 28 269-filter 1x1: 116 MB of weights against 9.5 MB of input): tiles are
+    // dealt per XCD -- workgroups b with the same b % 8 share an L2 -- so that XCD x owns filter tiles x, x + 8, ... (every
+    // weight byte enters ONE L2) and walks them in blocks of `pblk` pixel tiles whose input rows stay L2-resident meanwhile.
+    // 0 = plain order (filter tile fastest).  Needs gridDim.x % 8 == 0 and ksplit == 1; placement is speed only.
+    int xcd_order, tiles_m, pblk;
     int row0;          // fp16 matrix-core kernels: first GEMM row of this launch (tail launch behind the 256x256 kernel); tile t starts at row0 + (t / tiles_n) * BM
     unsigned long long *stamps;   // diagnostic builds (-DY2_F32_STAMPS): per-wave cycle counters
     // stride / out_h / out_w: fp32 matrix-core and direct kernels; size / pad / batch: direct kernel only

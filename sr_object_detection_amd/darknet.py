@@ -227,6 +227,7 @@ def lib():
     L.y2h_p8_stream_k_plan.argtypes = [C.c_long, C.c_int, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.y2h_stream_k_launches.restype = C.c_ulong
     L.y2h_tail_launches.restype = C.c_ulong
+    L.y2h_xcd_order_launches.restype = C.c_ulong
     _lib = L
     return L
 

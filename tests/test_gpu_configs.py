@@ -135,9 +135,10 @@ def test_darknet19_448_fp32_batch32_matches_reference(workdir, oracle):
     net.free()
 
 
-def test_darknet19_448_fp16_batch128_top5(workdir, oracle):
+def test_darknet19_448_fp16_batch128_top5(workdir, oracle, monkeypatch):
     """configs[4]: fp16 storage, fp32 accumulation; parity bar of SURVEY 8(d): identical top-5, probabilities within 1e-2
-    of the fp32 CPU reference -- for every one of the 128 batch items"""
+    of the fp32 CPU reference -- for every one of the 128 batch items.  At this size the 256x256 kernel's last, partial
+    round is finished by stream-K or by a small-tile tail launch: both really run here."""
     g = load_golden("darknet19_448_b8")
     batch = 128
     cfg, wts, _ = materialize(workdir, "darknet19", 448, batch, int(g["seed"]), float(g["head_gain"]))
@@ -145,7 +146,10 @@ def test_darknet19_448_fp16_batch128_top5(workdir, oracle):
     net = darknet.Network.parse_network_cfg(cfg)
     net.load_weights(wts)
     net.set_half(True)
-    out = net.network_predict(x).reshape(batch, 1000)
+    L = darknet.lib()
+    sk0, tl0 = L.y2h_stream_k_launches(), L.y2h_tail_launches()
+    out = net.network_predict(x).reshape(batch, 1000).copy()
+    assert L.y2h_stream_k_launches() > sk0 and L.y2h_tail_launches() > tl0
     names = _check_kernels_are_tested(net, half=True)
     ref = g["out"].reshape(-1, 1000)
     worst = 0.0
@@ -155,8 +159,16 @@ def test_darknet19_448_fp16_batch128_top5(workdir, oracle):
         assert np.abs(out[b] - r).max() < 1e-2, "batch item %d" % b
         assert set(oracle.top_k(out[b], 5)) == set(oracle.top_k(r, 5)), "batch item %d: top-5 differs" % b
         assert abs(float(out[b].sum()) - 1.0) < 1e-4
-    # identical frames give identical scores whatever their position in the batch
+    # Identical frames at different batch positions: a tail tile is summed in another order than a whole tile (pieces of a
+    # K range, or the 32x32x16 instruction of the small tile), so the scores agree to accumulation noise only ...
     for b in range(batch):
-        assert np.array_equal(out[b], out[which.index(which[b])])
+        assert np.abs(out[b] - out[which.index(which[b])]).max() < 1e-4
+    # ... and bit for bit with every tile walked whole (Y2_SK=0 Y2_TAIL=0: the plan is made per launch)
+    monkeypatch.setenv("Y2_SK", "0")
+    monkeypatch.setenv("Y2_TAIL", "0")
+    out2 = net.network_predict(x).reshape(batch, 1000)
+    for b in range(batch):
+        assert np.array_equal(out2[b], out2[which.index(which[b])])
+        assert np.abs(out2[b] - out[b]).max() < 1e-4
     print("darknet19_448 fp16 b128: max |dp| = %.3e; kernels %s" % (worst, sorted(set(names))))
     net.free()

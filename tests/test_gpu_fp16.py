@@ -154,3 +154,27 @@ def test_f16_mode_errors(workdir):
     out = net.network_predict(x)
     assert net.layer_kernel(0) == "conv_direct_f32"
     net.free()
+
+
+@pytest.mark.parametrize("filters,size,batch", [(64, 14, 3), (1000, 7, 2), (72, 5, 1), (40, 2, 2), (36, 14, 2)])
+def test_f16_avgpool_is_exact_on_integer_data(oracle, workdir, monkeypatch, filters, size, batch):
+    """avgpool_layer.c:40-54 on half activations: the 16-byte-load kernel (8 channels per lane, the pixels in four
+    contiguous quarters) and the scalar one both equal the oracle on integer data (every partial sum exact); 36 channels
+    take the scalar kernel (not a multiple of 8), 1000 are darknet19's"""
+    spec = [("conv", 16, 3, 0, "linear"), ("conv", filters, 1, 0, "linear"), ("avg",)]
+    cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 9900 + filters + size)
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    assert np.abs(on.layer_output(1)).max() <= 2048          # the pooled tensor is exact in half
+    on.close()
+    for scalar in (False, True):
+        if scalar:
+            monkeypatch.setenv("Y2_AVGPOOL_SCALAR", "1")
+        else:
+            monkeypatch.delenv("Y2_AVGPOOL_SCALAR", raising=False)
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        net.set_half(True)
+        out = net.network_predict(x)
+        net.free()
+        assert out.shape == ref.shape and np.array_equal(out, ref)

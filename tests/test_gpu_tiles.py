@@ -150,6 +150,25 @@ def test_f16_tile_scalar_store_path_is_exact(oracle, workdir, monkeypatch, tile,
 SK_CASES = [(5, 7, 7), (3, 3, 5), (12, 13, 13), (2, 7, 7), (7, 7, 7)]
 
 
+@pytest.mark.parametrize("grid", [16, 40])
+@pytest.mark.parametrize("pblk", [1, 3, 100])
+@pytest.mark.parametrize("tile,filters", [((64, 64), 64 * 20 + 40), ((128, 128), 128 * 10 + 24), ((192, 256), 256 * 9 + 40)],
+                         ids=lambda v: "%dx%d" % v if isinstance(v, tuple) else "n%d" % v)
+def test_f32_xcd_grouped_tile_order_is_exact(oracle, workdir, monkeypatch, tile, filters, pblk, grid):
+    """wide 1x1 heads (yolo9000's 28 269-filter layer, cfg/yolo9000.cfg:198-218): tiles are dealt per XCD -- workgroups with
+    the same b % 8 own filter tiles x, x + 8, ... and walk them in blocks of `pblk` pixel tiles -- instead of filter-tile
+    fastest.  Every tile must still be computed exactly once: equal to the oracle on integer data, with 10 / 11 / 21 filter
+    tiles (uneven over the eight XCDs), a partial last pixel block and more than one tile per workgroup."""
+    monkeypatch.setenv("Y2_XCD_ORDER", "1")
+    monkeypatch.setenv("Y2_XCD_PBLK", str(pblk))
+    before = darknet.lib().y2h_xcd_order_launches()
+    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=64, filters=filters, ksize=1, size=26, batch=2, tile=tile,
+                             pool=False, grid=grid, seed=80000 + tile[0] + pblk * 7 + grid)
+    assert name == "conv_mfma_f32_%dx%dx32_k1" % tile, name
+    assert darknet.lib().y2h_xcd_order_launches() > before
+    assert np.array_equal(out, ref)
+
+
 @pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
 @pytest.mark.parametrize("ksize,cin", [(3, 128), (1, 256), (1, 64)], ids=["k3_nk18", "k1_nk4", "k1_nk1"])
 @pytest.mark.parametrize("sk", SK_CASES, ids=lambda c: "sk%d_wg%d_grid%d" % c)
