@@ -338,6 +338,21 @@ def main():
         sys.exit("bench: %d ranks but only %d GPU(s) visible (one process per GPU; Y2_BENCH_SHARE_GPU=1 rehearses on one)" % (world, ndev))
     device_index = local_rank % ndev if share else local_rank
     torch.cuda.set_device(device_index)
+    # Host side of rank r next to GPU r: pin this process to the cores of the NUMA node the GPU's PCI function hangs off
+    # (the feed of 142 MB per batch and the fetch of the detections are the only host work; SURVEY section 7 names the host
+    # feed as the scaling risk).  Skipped silently where /sys does not say (containers without the topology).
+    numa_node = None
+    if os.environ.get("Y2_BENCH_NUMA", "1") != "0":
+        numa_node, cpus = darknet.numa_cpus_of_device(device_index)
+        if cpus:
+            try:
+                allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+                if allowed:
+                    os.sched_setaffinity(0, allowed)
+                else:
+                    numa_node = None
+            except OSError:
+                numa_node = None
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -369,9 +384,17 @@ def main():
         net.load_weights(wts)
         net.prepare()
     bcast_how, bcast_ms = "none (1 rank)", None
+    comm_ranks = 1
     if world > 1:
+        comm_ranks = dist.get_world_size()                 # (the C-ABI transport replaces it with ncclCommCount below)
         # replicate the packed weights: ONE broadcast of the kernel-layout arena, in place on the arena pointer
         arena_ptr, arena_bytes = net.weights_arena()
+        # every rank must have laid its arena out as rank 0 did (same cfg, same modes): neither RCCL nor torch compares
+        # counts across ranks.  y2_broadcast_weights does this handshake itself; for the torch transports it is done here.
+        layouts = [None] * world
+        dist.all_gather_object(layouts, net.weights_layout())
+        if any(l != layouts[0] for l in layouts):
+            sys.exit("bench: rank %d: weight arena layouts differ across ranks: %s" % (rank, layouts))
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -382,6 +405,7 @@ def main():
             uid = [darknet.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             comm = darknet.comm_init_rank(world, uid[0], rank, device_index)
+            comm_ranks = darknet.comm_count(comm)[0]       # ncclCommCount of the communicator the arena travels on
             net.broadcast_weights(comm, 0)
             darknet.comm_destroy(comm)
             bcast_how = "RCCL ncclBroadcast via the C-ABI (y2_broadcast_weights, %s), in place on the arena" % darknet.comm_library()
@@ -576,6 +600,32 @@ def main():
         np.savez(args.dump_dets + ".rank%d.npz" % rank, counts=np.asarray(counts),
                  **{"dets_%d" % b: dets[b] for b in range(len(dets))})
 
+    # N > 1, outside the timed region: every rank's last batch is recomputed on rank 0 (same frames: seed 0xC0FFEE + r * batch,
+    # same arena bytes, same kernels) and must come out bit for bit -- a rank whose replica, frames or device misbehaved
+    # shows here, not in a throughput number.  Also what each rank ran on.
+    shards_verified, rank_devices = None, None
+    if world > 1:
+        def digest(d_, c_):
+            if is_detector:
+                return [np.asarray(c_).tobytes()] + [np.ascontiguousarray(d_[b]).tobytes() for b in range(len(d_))]
+            return [np.ascontiguousarray(d_).tobytes()]
+        mine = digest(dets, counts)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (darknet.device_name(), darknet.device_pci_bus_id(), numa_node, mine))
+        if rank == 0:
+            rank_devices = ["%s @%s numa %s" % (g[0], g[1] or "?", "?" if g[2] is None else g[2]) for g in gathered]
+            shards_verified = 1
+            for r in range(1, world):
+                xr = torch.from_numpy(synth.image_batch(batch, 3, size, size, seed=0xC0FFEE + r * batch)).cuda()
+                net.forward_device(xr.data_ptr())
+                enqueue_results()
+                dr, cr = fetch_results()
+                if digest(dr, cr) != gathered[r][3]:
+                    sys.exit("bench: rank %d's last batch differs from its recomputation on rank 0" % r)
+                shards_verified += 1
+                del xr
+        dist.barrier()
+
     if rank == 0:
         total_images = world * batch * args.steps
         dom = max(per_kernel_ms, key=lambda k: per_kernel_ms[k]) if per_kernel_ms else None
@@ -602,6 +652,7 @@ def main():
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if half else "f32", "data": "synthetic",
+            "ranks": comm_ranks, "shards_verified": shards_verified, "rank_devices": rank_devices,
             "config": {"workload": "%s %dx%d batch %d per GPU: %s, %s" % (
                            name + ".cfg", size, size, batch, what,
                            "inputs in pinned host memory (PCIe-inclusive)" if args.host_input == "only" else "inputs resident in HBM"),

@@ -308,6 +308,12 @@ int y2_comm_unique_id(void *id_out);
 int y2_comm_init_rank(void **comm, int nranks, const void *id, int rank, int device);
 int y2_comm_destroy(void *comm);
 int y2_broadcast_weights(network *net, void *comm, int root);
+/* ranks of `comm` and this process's rank in it, as RCCL reports them (ncclCommCount / ncclCommUserRank) */
+int y2_comm_count(void *comm, int *nranks, int *rank);
+/* (layout signature, bytes) of the weight arena under the current plan.  y2_broadcast_weights compares them across the
+ * ranks before it moves a byte (RCCL itself checks neither counts nor types); a launcher that replicates the arena by
+ * other means must do the same. */
+int y2_weights_layout(network *net, unsigned long long *signature, size_t *bytes);
 /* Pinned, multi-buffered host feed (replaces the per-call cudaMalloc + pageable H2D + cudaFree of
  * network_kernels.cu:392-405): `slots` pairs of (pinned host buffer, HBM buffer) of slot_bytes each (0 = one batch of
  * float NCHW frames) and a copy stream.  The producer writes a batch into y2_feed_host(net, s), y2_feed_submit starts

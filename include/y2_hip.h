@@ -62,6 +62,9 @@ int         y2h_set_device(int dev);
 int         y2h_get_device(int *dev);
 const char *y2h_last_error(void);
 const char *y2h_device_name(void);
+/* PCI address ("0000:c1:00.0") of device `dev` (< 0: the current one), "" if unknown: lets a launcher pin a rank's host
+ * threads to the NUMA node of its GPU (/sys/bus/pci/devices/<address>/numa_node) */
+const char *y2h_device_pci_bus_id(int dev);
 int         y2h_malloc(void **ptr, size_t bytes);
 int         y2h_free(void *ptr);
 int         y2h_host_alloc(void **ptr, size_t bytes);           /* pinned host memory */

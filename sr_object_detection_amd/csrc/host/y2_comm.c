@@ -30,6 +30,7 @@ typedef int (*fn_comm_destroy)(void *);
 typedef int (*fn_broadcast)(const void *, void *, size_t, int, int, void *, void *);
 typedef const char *(*fn_error_string)(int);
 typedef int (*fn_comm_count)(void *, int *);
+typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, void *);
 
 static struct {
     void *handle;
@@ -37,6 +38,7 @@ static struct {
     fn_comm_init_rank comm_init_rank;
     fn_comm_destroy comm_destroy;
     fn_broadcast broadcast;
+    fn_all_reduce all_reduce;
     fn_error_string error_string;
     fn_comm_count comm_count, comm_user_rank;
     char path[512];
@@ -71,10 +73,11 @@ static int rccl_bind(void)
     g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(g_rccl.handle, "ncclCommInitRank");
     g_rccl.comm_destroy = (fn_comm_destroy)dlsym(g_rccl.handle, "ncclCommDestroy");
     g_rccl.broadcast = (fn_broadcast)dlsym(g_rccl.handle, "ncclBroadcast");
+    g_rccl.all_reduce = (fn_all_reduce)dlsym(g_rccl.handle, "ncclAllReduce");
     g_rccl.error_string = (fn_error_string)dlsym(g_rccl.handle, "ncclGetErrorString");
     g_rccl.comm_count = (fn_comm_count)dlsym(g_rccl.handle, "ncclCommCount");
     g_rccl.comm_user_rank = (fn_comm_count)dlsym(g_rccl.handle, "ncclCommUserRank");
-    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.broadcast || !g_rccl.comm_count ||
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.broadcast || !g_rccl.all_reduce || !g_rccl.comm_count ||
         !g_rccl.comm_user_rank) {
         y2_fail("%s does not export the RCCL entry points", g_rccl.path);
         dlclose(g_rccl.handle);
@@ -122,22 +125,39 @@ int y2_comm_destroy(void *comm)
     return 0;
 }
 
+/* ranks of the communicator and this process's rank in it, as RCCL itself reports them (ncclCommCount / ncclCommUserRank):
+ * what a benchmark line quotes to show that the collective really spanned N processes */
+int y2_comm_count(void *comm, int *nranks, int *rank)
+{
+    int rc, n = 0, r = -1;
+    if (!comm) { y2_fail("y2_comm_count: NULL communicator"); return -1; }
+    if (rccl_bind() != 0) return -1;
+    if ((rc = g_rccl.comm_count(comm, &n)) != 0 || (rc = g_rccl.comm_user_rank(comm, &r)) != 0) {
+        y2_fail("y2_comm_count: not an RCCL communicator of %s: %s", g_rccl.path, rccl_err(rc));
+        return -1;
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    return 0;
+}
+
 /* Replicate root's packed weights to every rank of `comm`: one in-place ncclBroadcast of the arena on the engine's
- * stream.  Root must have loaded its weights; the other ranks need no load_weights at all (their arena is laid out by
- * the same plan and declared resident afterwards).  All ranks must have parsed the same cfg with the same modes:
- * the byte counts are compared through the collective's own count check (a mismatch is an RCCL error, not silent). */
+ * stream.  Root must hold weights (load_weights, or a replica's resident arena); the other ranks need no load_weights at
+ * all (their arena is laid out by the same plan and declared resident afterwards).  All ranks must have parsed the same
+ * cfg with the same modes (strict / fp16 / fusion switches change the arena layout).  RCCL compares neither byte counts
+ * nor datatypes across ranks -- a rank with another layout would hang, truncate, or fill its arena with bytes of a
+ * foreign layout -- so a 16-byte handshake runs first on the same communicator: root's (arena bytes, layout signature)
+ * is broadcast, every rank compares it with its own, and an all-reduce of the verdicts makes EVERY rank fail together
+ * (nobody is left waiting in the big broadcast). */
 int y2_broadcast_weights(network *net, void *comm, int root)
 {
     y2_engine *e;
-    void *arena = NULL;
+    void *arena = NULL, *d_hs = NULL;
     size_t bytes = 0;
-    int rc, nranks = 0, rank = -1;
+    unsigned long long hs[4];        /* [0] bytes, [1] signature, [2..3] as int: this rank's verdict / the sum of verdicts */
+    int rc, nranks = 0, rank = -1, ok, agreed = 0;
     if (!net || !comm) { y2_fail("y2_broadcast_weights: NULL network or communicator"); return -1; }
-    if (rccl_bind() != 0) return -1;
-    if ((rc = g_rccl.comm_count(comm, &nranks)) != 0 || (rc = g_rccl.comm_user_rank(comm, &rank)) != 0) {
-        y2_fail("y2_broadcast_weights: not an RCCL communicator of %s: %s", g_rccl.path, rccl_err(rc));
-        return -1;
-    }
+    if (y2_comm_count(comm, &nranks, &rank) != 0) return -1;
     if (root < 0 || root >= nranks) { y2_fail("y2_broadcast_weights: root %d of %d ranks", root, nranks); return -1; }
     if (rank == root) {
         if (y2_prepare(net) != 0) return -1;             /* plan + pack + upload the host weights */
@@ -145,11 +165,60 @@ int y2_broadcast_weights(network *net, void *comm, int root)
     if (y2_weights_arena(net, &arena, &bytes) != 0) return -1;
     e = y2_engine_of(net);
     if (!arena || !bytes || !e->stream) { y2_fail("y2_broadcast_weights: the network has no weight arena"); return -1; }
+    /* handshake */
+    hs[0] = (unsigned long long)bytes; hs[1] = (unsigned long long)e->arena_sig; hs[2] = hs[3] = 0;
+    if (y2h_malloc(&d_hs, sizeof hs) != 0) { y2_fail("y2_broadcast_weights: %s", y2h_last_error()); return -1; }
+    if (y2h_memcpy_h2d(d_hs, hs, sizeof hs, e->stream) != 0 || y2h_stream_sync(e->stream) != 0) goto hip_fail;
+    if ((rc = g_rccl.broadcast(d_hs, d_hs, 16, /* ncclUint8 */ 1, root, comm, e->stream)) != 0) {
+        y2_fail("ncclBroadcast of the layout handshake: %s", rccl_err(rc));
+        y2h_free(d_hs);
+        return -1;
+    }
+    {
+        unsigned long long got[2] = {0, 0};
+        int verdict[2];
+        if (y2h_memcpy_d2h(got, d_hs, sizeof got, e->stream) != 0 || y2h_stream_sync(e->stream) != 0) goto hip_fail;
+        ok = got[0] == hs[0] && got[1] == hs[1];
+        verdict[0] = ok; verdict[1] = 0;
+        if (y2h_memcpy_h2d((char *)d_hs + 16, verdict, sizeof verdict, e->stream) != 0 || y2h_stream_sync(e->stream) != 0) goto hip_fail;
+        if ((rc = g_rccl.all_reduce((char *)d_hs + 16, (char *)d_hs + 20, 1, /* ncclInt32 */ 2, /* ncclSum */ 0, comm, e->stream)) != 0) {
+            y2_fail("ncclAllReduce of the layout verdicts: %s", rccl_err(rc));
+            y2h_free(d_hs);
+            return -1;
+        }
+        if (y2h_memcpy_d2h(verdict, (char *)d_hs + 16, sizeof verdict, e->stream) != 0 || y2h_stream_sync(e->stream) != 0) goto hip_fail;
+        agreed = verdict[1];
+        y2h_free(d_hs); d_hs = NULL;
+        if (agreed != nranks) {
+            if (!ok) y2_fail("y2_broadcast_weights: rank %d laid its arena out differently from root %d (%llu bytes, signature %016llx "
+                             "against %llu, %016llx): same cfg, batch-independent modes (strict / fp16 / fusion) must match on every rank",
+                             rank, root, hs[0], hs[1], got[0], got[1]);
+            else y2_fail("y2_broadcast_weights: %d of %d ranks have another arena layout than root %d; nothing was broadcast",
+                         nranks - agreed, nranks, root);
+            return -1;
+        }
+    }
     if ((rc = g_rccl.broadcast(arena, arena, bytes, /* ncclUint8 */ 1, root, comm, e->stream)) != 0) {
         y2_fail("ncclBroadcast of the %zu-byte weight arena: %s", bytes, rccl_err(rc));
         return -1;
     }
     if (y2h_stream_sync(e->stream) != 0) { y2_fail("y2_broadcast_weights: %s", y2h_last_error()); return -1; }
     if (rank != root) y2_weights_resident(net);
+    return 0;
+hip_fail:
+    y2_fail("y2_broadcast_weights: %s", y2h_last_error());
+    if (d_hs) y2h_free(d_hs);
+    return -1;
+}
+
+/* (arena bytes, layout signature) of the current plan: what the handshake above compares; launchers that move the arena
+ * by other means (torch.distributed on a view of it, MPI) exchange and compare these two numbers first */
+int y2_weights_layout(network *net, unsigned long long *signature, size_t *bytes)
+{
+    void *arena = NULL;
+    size_t b = 0;
+    if (!net || y2_weights_arena(net, &arena, &b) != 0) return -1;
+    if (signature) *signature = (unsigned long long)y2_engine_of(net)->arena_sig;
+    if (bytes) *bytes = b;
     return 0;
 }

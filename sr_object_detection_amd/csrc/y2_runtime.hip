@@ -36,6 +36,16 @@ extern "C" const char *y2h_device_name(void)
     return g_name;
 }
 
+// "0000:c1:00.0" of device `dev` (dev < 0: the current device); "" when the runtime does not report it
+extern "C" const char *y2h_device_pci_bus_id(int dev)
+{
+    static thread_local char bdf[32];
+    bdf[0] = 0;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return bdf;
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) != hipSuccess) bdf[0] = 0;
+    return bdf;
+}
+
 // Debug aid (env Y2_GUARD=1, e.g. for a whole `pytest -m gpu` run): every device buffer gets a 4 KB canary in front of and
 // behind it, filled with 0xA5 at allocation and checked when the buffer is freed (hipFree has waited for the device by
 // then); a kernel that wrote outside its buffer is reported with the buffer's size and the first damaged offset.  Off, the

@@ -199,6 +199,8 @@ def lib():
     L.y2_comm_init_rank.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.y2_comm_destroy.argtypes = [C.c_void_p]
     L.y2_broadcast_weights.argtypes = [C.POINTER(CNetwork), C.c_void_p, C.c_int]
+    L.y2_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.y2_weights_layout.argtypes = [C.POINTER(CNetwork), C.POINTER(C.c_ulonglong), C.POINTER(C.c_size_t)]
     L.y2_network_predict_device.restype = C.POINTER(C.c_float)
     L.y2_network_predict_device.argtypes = [CNetwork, C.c_void_p]
     L.y2_forward_device.argtypes = [CNetwork, C.c_void_p]
@@ -216,6 +218,8 @@ def lib():
     L.y2h_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     L.y2h_device_count.restype = C.c_int
     L.y2h_device_name.restype = C.c_char_p
+    L.y2h_device_pci_bus_id.restype = C.c_char_p
+    L.y2h_device_pci_bus_id.argtypes = [C.c_int]
     L.y2h_last_error.restype = C.c_char_p
     L.y2h_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     L.y2h_free.argtypes = [C.c_void_p]
@@ -431,6 +435,13 @@ class Network:
         if lib().y2_weights_arena(C.byref(self.net), C.byref(p), C.byref(n)) != 0:
             raise Y2Error("y2_weights_arena: " + _check())
         return p.value, n.value
+
+    def weights_layout(self):
+        """(layout signature, bytes) of the weight arena: equal on every rank or the replication is refused"""
+        sig, b = C.c_ulonglong(0), C.c_size_t(0)
+        if lib().y2_weights_layout(C.byref(self.net), C.byref(sig), C.byref(b)) != 0:
+            raise Y2Error("y2_weights_layout: " + _check())
+        return int(sig.value), int(b.value)
 
     def weights_resident(self) -> None:
         lib().y2_weights_resident(C.byref(self.net))
@@ -758,6 +769,14 @@ def comm_init_rank(nranks: int, uid: bytes, rank: int, device: int) -> int:
     return comm.value
 
 
+def comm_count(comm: int):
+    """(ranks, this rank) of an RCCL communicator, as ncclCommCount / ncclCommUserRank report them"""
+    n, r = C.c_int(0), C.c_int(-1)
+    if lib().y2_comm_count(C.c_void_p(comm), C.byref(n), C.byref(r)) != 0:
+        raise Y2Error("y2_comm_count: " + _check())
+    return n.value, r.value
+
+
 def comm_destroy(comm: int) -> None:
     if lib().y2_comm_destroy(C.c_void_p(comm)) != 0:
         raise Y2Error("y2_comm_destroy: " + _check())
@@ -776,3 +795,27 @@ def device_count() -> int:
 
 def device_name() -> str:
     return lib().y2h_device_name().decode()
+
+
+def device_pci_bus_id(dev: int = -1) -> str:
+    """PCI address of a device ("0000:c1:00.0"; dev < 0: the current one); "" if the runtime will not say"""
+    return lib().y2h_device_pci_bus_id(dev).decode()
+
+
+def numa_cpus_of_device(dev: int = -1):
+    """(NUMA node, cpu list) of the GPU's PCI function as /sys exposes them, or (None, None).  The host feed of rank r
+    (142 MB per 608x608 fp32 batch) should run on the cores next to GPU r's root port."""
+    bdf = device_pci_bus_id(dev).lower()
+    if not bdf:
+        return None, None
+    try:
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return None, None
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus += list(range(int(lo), int(hi or lo) + 1))
+        return node, cpus
+    except (OSError, ValueError):
+        return None, None

@@ -30,7 +30,10 @@ def rank_env(rank: int, world: int, port: int, base=None) -> dict:
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    # dmabuf IPC between the ranks' processes: the runtime switch is read by libhsa-runtime64 (the string is in the ROCm 7.2
+    # library of this image), and this pool's host driver supports only dmabuf IPC -- the environment exports 0 already, here
+    # and on the GPU boxes; inherited when set, never overridden (without it RCCL's hipIpcGetMemHandle fails between processes)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     return env
 

@@ -94,8 +94,11 @@ def test_rccl_c_abi_broadcast_single_rank(workdir):
     uid = darknet.comm_unique_id()
     assert len(uid) == 128 and any(uid)
     comm = darknet.comm_init_rank(1, uid, 0, 0)
-    net.broadcast_weights(comm, 0)
+    assert darknet.comm_count(comm) == (1, 0)                  # ncclCommCount / ncclCommUserRank
+    net.broadcast_weights(comm, 0)                             # layout handshake (broadcast + all-reduce) + the arena
     assert np.array_equal(net.network_predict(x), want)
+    sig, nbytes = net.weights_layout()
+    assert sig != 0 and nbytes == net.weights_arena()[1]
     with pytest.raises(darknet.Y2Error, match="root"):
         net.broadcast_weights(comm, 3)
     darknet.comm_destroy(comm)
@@ -117,6 +120,7 @@ def test_bench_launches_two_ranks_itself_and_rank1_matches_a_single_process(work
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["value"] > 0
     assert "broadcast" in line["config"]["weight_broadcast"]
+    assert line["ranks"] == 2 and line["shards_verified"] == 2 and len(line["rank_devices"]) == 2
     # single process, frames 8..15 (global image index = rank * batch + i, seed 0xC0FFEE + index)
     import bench
     cfg = bench.write_cfg(str(tmp_path), "yolo", 416, 8)
@@ -134,6 +138,24 @@ def test_bench_launches_two_ranks_itself_and_rank1_matches_a_single_process(work
     r0 = np.load(dump + ".rank0.npz")
     assert not np.array_equal(r0["counts"], counts) or not np.array_equal(r0["dets_0"], dets[0])     # other frames
     net.free()
+
+
+def test_bench_five_rank_rehearsal_on_one_gpu(tmp_path):
+    """the launcher, the ports, the rank-0 relay, the arena broadcast, the per-rank frame shards and the teardown at the
+    largest rank count one box allows (the pool's process guard admits six processes on a card and this test process is
+    one of them; the driver's real run is eight ranks on eight GPUs over RCCL): every rank's last batch must equal its
+    recomputation on rank 0, bit for bit (shards_verified), and the line must report the five ranks"""
+    env = dict(os.environ, Y2_BENCH_BACKEND="gloo", Y2_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--workload", "yolo416_b8", "--steps", "3",
+                        "--warmup", "1", "--cpu-iters", "0", "--host-input", "off", "--autotune", "0"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 5 and line["ranks"] == 5 and line["config"]["global_batch"] == 40
+    assert line["shards_verified"] == 5 and len(line["rank_devices"]) == 5
+    assert line["value"] > 0 and line["scaling"] == "weak"
 
 
 def test_pinned_feed_matches_resident_and_overlaps(workdir):
