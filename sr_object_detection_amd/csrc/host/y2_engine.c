@@ -1005,10 +1005,18 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
     if (net->c <= 0 || net->h <= 0 || net->w <= 0) { y2_fail("network input must be an image (h,w,c > 0)"); return -1; }
     if (!d_input_nchw) d_input_nchw = e->d_in_nchw;     /* filled by y2_ingest_u8 */
     if (!e->graph_on || e->timing || e->strict) return enqueue_forward(net, d_input_nchw);
+    /* y2_set_detect_overlap together with graph replay: the wait that keeps this forward's region layer from overwriting
+     * d_region while the previous batch's decode / NMS still read it on det_stream cannot live inside the graph (it would
+     * be captured once, against whatever det_pending was then, on an event recorded outside the capture).  It is issued
+     * here, in front of the capture and of every replay: the whole forward waits, slightly more than the eager path's
+     * wait in front of the region layer, and the captured sequence itself carries no wait (e->capturing). */
+    if (e->det_overlap && e->det_pending == 1 && e->ev_det) HIPCALL(y2h_stream_wait_event(e->stream, e->ev_det));
     if (!e->graph || e->graph_src != d_input_nchw) {
         if (e->graph) { y2h_graph_destroy(e->graph); e->graph = NULL; }
         HIPCALL(y2h_graph_begin(e->stream));
-        if (enqueue_forward(net, d_input_nchw) != 0) { y2h_graph_abort(e->stream); return -1; }
+        e->capturing = 1;
+        if (enqueue_forward(net, d_input_nchw) != 0) { e->capturing = 0; y2h_graph_abort(e->stream); return -1; }
+        e->capturing = 0;
         if (y2h_graph_end(e->stream, &e->graph) != 0) { e->graph = NULL; y2_fail("hipGraph capture of the forward pass failed: %s", y2h_last_error()); return -1; }
         e->graph_src = d_input_nchw;
     }
@@ -1021,9 +1029,14 @@ static int enqueue_forward(network *net, const float *d_input_nchw)
     y2_engine *e = y2_engine_of(net);
     int i, k;
     e->cur_input = d_input_nchw;
-    if (e->in_halo == 3 && ((uintptr_t)d_input_nchw % 16) == 0)
-        ;                                                       /* the first layer reads d_input_nchw */
-    else if (e->in_halo == 3) { y2_fail("the first layer needs a 16-byte aligned network input"); return -1; }
+    if (e->in_halo == 3 && (!e->half || ((uintptr_t)d_input_nchw % 16) == 0))
+        ;                                                       /* the first layer reads d_input_nchw (fp32 kernel: dword loads, any float pointer) */
+    else if (e->in_halo == 3) {
+        /* the fp16 first-layer kernel reads the planes with 16-byte loads: a caller's pointer that is not 16-byte aligned
+         * (a frame slice of an odd-sized batch) goes through the engine's own input slot */
+        if (d_input_nchw != e->d_in_nchw) HIPCALL(y2h_memcpy_d2d(e->d_in_nchw, d_input_nchw, e->in_floats * sizeof(float), e->stream));
+        e->cur_input = e->d_in_nchw;
+    }
     else if (e->in_halo == 2)
         HIPCALL(y2h_nchw_to_nhwc4_halo_f16(d_input_nchw, e->d_in_nhwc, net->batch, net->c, net->h, net->w, e->stream));
     else if (e->in_halo)
@@ -1085,7 +1098,7 @@ static int enqueue_forward(network *net, const float *d_input_nchw)
         case REGION: {
             tree *t = l->softmax_tree;
             /* y2_set_detect_overlap: the previous batch's decode / NMS may still be reading d_region on det_stream */
-            if (e->det_overlap && e->det_pending == 1 && i == e->out_layer) HIPCALL(y2h_stream_wait_event(e->stream, e->ev_det));
+            if (e->det_overlap && e->det_pending == 1 && i == e->out_layer && !e->capturing) HIPCALL(y2h_stream_wait_event(e->stream, e->ev_det));
             HIPCALL(y2h_region_forward(x, ldx, d->d_region, l->batch, l->h * l->w, l->n, l->classes, l->coords, l->softmax,
                                        t ? t->groups : 0, d->d_tree_gsize, d->d_tree_goff, e->stream));
         } break;

@@ -77,6 +77,7 @@ typedef struct y2_engine {
     /* weight arena */
     unsigned char *arena;
     size_t arena_bytes;
+    int capturing;             /* inside the hipGraph capture of a forward pass (no cross-stream waits may be recorded) */
     uint64_t arena_sig;        /* hash of the per-layer offsets / forms the arena was laid out with (0: none yet) */
     /* io buffers */
     float *d_in_nchw, *d_in_nhwc;

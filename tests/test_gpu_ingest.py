@@ -227,6 +227,86 @@ def test_detect_overlap_mode_gives_the_same_detections(workdir, netname, size, b
     net.free()
 
 
+def test_detect_overlap_together_with_graph_replay(workdir):
+    """y2_set_detect_overlap + y2_set_graph: the wait that protects the region tensor from the next forward cannot be part
+    of the captured graph; it is issued in front of every replay.  The benchmark's pipelined loop over eight batches that
+    alternate between two device buffers (replay, re-record, replay ...) and then over ONE buffer whose contents change
+    (pure replay) must give every batch's own detections -- also for the tree head, whose decode rewrites the region
+    tensor in place on the detect stream."""
+    import os
+    import torch
+    from sr_object_detection_amd import synth, zoo
+    for netname, size, batch, thresh in (("mini-mfma", 64, 3, 0.3), ("yolo", 160, 4, 0.2)):
+        cfg = os.path.join(workdir, "ovg_%s.cfg" % netname)
+        open(cfg, "w").write(zoo.cfg_text(netname, size, size, batch))
+        wts = os.path.join(workdir, "ovg_%s.weights" % netname)
+        synth.write_weights(wts, zoo.resolve(netname, size), 5 if netname == "mini-mfma" else 831)
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        host = [synth.image_batch(batch, 3, size, size, seed=70 + i) for i in range(8)]
+        frames = [torch.from_numpy(h).cuda() for h in host]
+        want = []
+        for f in frames:
+            net.forward_device(f.data_ptr())
+            want.append(net.detect_resident(thresh, 0.4))
+        assert len({int(c.sum()) for _, c in want}) > 1
+        net.set_detect_overlap(True)
+        net.set_graph(True)
+        one = torch.empty_like(frames[0])
+        for mode in ("two buffers", "one buffer"):
+            def feed(i):
+                if mode == "one buffer":
+                    torch.cuda.synchronize()                 # (the test's own copy must not race the previous forward)
+                    one.copy_(frames[i])
+                    torch.cuda.synchronize()
+                    return one.data_ptr()
+                return frames[i].data_ptr()
+            got = []
+            net.forward_device(feed(0))
+            net.detect_enqueue(thresh, 0.4)
+            for i in range(1, 8):
+                net.forward_device(feed(i))
+                got.append(net.detect_fetch())
+                net.detect_enqueue(thresh, 0.4)
+            got.append(net.detect_fetch())
+            for k, ((gd, gc), (wd, wc)) in enumerate(zip(got, want)):
+                assert np.array_equal(gc, wc), "%s, %s: batch %d" % (netname, mode, k)
+                for a, b in zip(gd, wd):
+                    assert np.array_equal(a, b)
+        net.free()
+
+
+def test_misaligned_device_input_is_staged_not_refused(workdir):
+    """a device input pointer that is not 16-byte aligned (frame slice of an odd-sized batch: 75x75x3 floats = 12 mod 16
+    bytes): the fp32 first-layer kernel reads it with dword loads as it is, the fp16 one gets it through the engine's own
+    aligned input slot -- same bits as the aligned call in both modes"""
+    import os
+    import torch
+    from sr_object_detection_amd import synth, zoo
+    spec = [("conv", 32, 3, 1, "leaky"), ("max", 2, 2), ("conv", 64, 3, 1, "leaky"), ("conv", 30, 1, 0, "linear")]
+    size = 76
+    cfg = os.path.join(workdir, "misal.cfg")
+    open(cfg, "w").write(zoo.cfg_text("misal", size, size, 1, spec=spec))
+    wts = os.path.join(workdir, "misal.weights")
+    synth.write_weights(wts, zoo.resolve(spec, size), 5)
+    x = synth.image_batch(1, 3, size, size, seed=3)
+    buf = torch.zeros(x.size + 8, dtype=torch.float32, device="cuda")
+    for half in (False, True):
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        net.set_half(half)
+        want = net.network_predict(x).copy()
+        assert "nchw" in net.layer_kernel(0), net.layer_kernel(0)
+        for off in (1, 3, 4):
+            view = buf[off:off + x.size]
+            view.copy_(torch.from_numpy(x.reshape(-1)))
+            torch.cuda.synchronize()
+            assert (view.data_ptr() % 16 != 0) == (off % 4 != 0)
+            got = net.predict_device(view.data_ptr())
+            assert np.array_equal(got.reshape(want.shape), want), "half=%s offset %d floats" % (half, off)
+        net.free()
+
+
 def test_output_enqueue_fetch_matches_predict_device(workdir):
     """y2_output_enqueue / y2_output_fetch (the classifier's overlapped host copy): batch i's scores fetched after batch
     i+1's forward was enqueued equal y2_network_predict_device's"""
