@@ -69,7 +69,11 @@ int         y2h_malloc(void **ptr, size_t bytes);
 int         y2h_free(void *ptr);
 int         y2h_host_alloc(void **ptr, size_t bytes);           /* pinned host memory */
 int         y2h_host_free(void *ptr);
-int         y2h_host_register(void *ptr, size_t bytes);         /* pin an existing host allocation */
+/* pin an existing host allocation.  HAZARD (profiles/r02_notes.md): only register buffers that own their pages -- mmap'ed
+ * or page-aligned AND page-padded.  A registered range that ends inside a heap page makes the runtime treat a pageable
+ * buffer that malloc placed in the rest of that page as pinned: an asynchronous copy from it then faults on the GPU.
+ * The engine itself never registers memory (its staging buffers come from y2h_host_alloc). */
+int         y2h_host_register(void *ptr, size_t bytes);
 int         y2h_host_unregister(void *ptr);
 int         y2h_memcpy_h2d(void *dst, const void *src, size_t bytes, y2h_stream s);
 int         y2h_memcpy_d2h(void *dst, const void *src, size_t bytes, y2h_stream s);

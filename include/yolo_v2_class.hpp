@@ -7,6 +7,7 @@
 // OpenCV convenience overloads of the reference (hpp:59-143) are header-only
 // glue around detect(image_t) and are provided under the same OPENCV guard.
 #pragma once
+#include <cstdlib>
 #include <deque>
 #include <memory>
 #include <stdexcept>
@@ -59,24 +60,54 @@ public:
                                                  float thresh = 0.2f, bool bgr = true);
 
 #ifdef OPENCV
-    // BGR 8-bit cv::Mat -> resized planar RGB float image -> detect -> boxes scaled back to mat's size
+    // The OpenCV convenience surface of the reference (yolo_v2_class.hpp:59-92), same names, signatures and results, so
+    // that yolo_console_dll.cpp:137,148 (det_image = detector.mat_to_image_resize(frame); detector.detect_resized(
+    // *det_image, frame_size, 0.24, true)) compiles unchanged.  Written against cv::Mat only (the reference goes through
+    // the C-API IplImage, which OpenCV 4 no longer ships).
     std::vector<bbox_t> detect(cv::Mat mat, float thresh = 0.2f, bool use_mean = false)
     {
         if (mat.data == NULL) throw std::runtime_error("Image is empty");
-        cv::Mat small;
-        cv::resize(mat, small, cv::Size(get_net_width(), get_net_height()));
-        image_t im;
-        im.h = small.rows; im.w = small.cols; im.c = small.channels();
-        std::vector<float> planes((size_t)im.h * im.w * im.c);
-        for (int k = 0; k < im.c; ++k)
-            for (int y = 0; y < im.h; ++y)
-                for (int x = 0; x < im.w; ++x)
-                    planes[((size_t)(im.c - 1 - k) * im.h + y) * im.w + x] = (float)(small.ptr<unsigned char>(y)[x * im.c + k] / 255.);
-        im.data = planes.data();
-        std::vector<bbox_t> out = detect(im, thresh, use_mean);
-        const float wk = (float)mat.cols / im.w, hk = (float)mat.rows / im.h;
-        for (auto &b : out) { b.x *= wk; b.w *= wk; b.y *= hk; b.h *= hk; }
-        return out;
+        auto image_ptr = mat_to_image_resize(mat);
+        return detect_resized(*image_ptr, mat.size(), thresh, use_mean);
+    }
+
+    // detect on an image already at network size; boxes scaled back to the frame it was resized from (hpp:67-75)
+    std::vector<bbox_t> detect_resized(image_t img, cv::Size init_size, float thresh = 0.2f, bool use_mean = false)
+    {
+        if (img.data == NULL) throw std::runtime_error("Image is empty");
+        std::vector<bbox_t> boxes = detect(img, thresh, use_mean);
+        const float wk = (float)init_size.width / img.w, hk = (float)init_size.height / img.h;
+        for (auto &b : boxes) { b.x *= wk; b.w *= wk; b.y *= hk; b.h *= hk; }
+        return boxes;
+    }
+
+    // cv::resize to the network size, then mat_to_image (hpp:77-83)
+    std::shared_ptr<image_t> mat_to_image_resize(cv::Mat mat) const
+    {
+        if (mat.data == NULL) return std::shared_ptr<image_t>(NULL);
+        cv::Mat det_mat;
+        cv::resize(mat, det_mat, cv::Size(get_net_width(), get_net_height()));
+        return mat_to_image(det_mat);
+    }
+
+    // 8-bit interleaved BGR(A) -> planar float, value / 255., channels 0 and 2 exchanged (hpp:85-92,96-141); the image
+    // frees itself with the last shared_ptr
+    static std::shared_ptr<image_t> mat_to_image(cv::Mat img)
+    {
+        std::shared_ptr<image_t> image_ptr(new image_t, [](image_t *im) { free_image(*im); delete im; });
+        const int h = img.rows, w = img.cols, c = img.channels();
+        image_ptr->h = h; image_ptr->w = w; image_ptr->c = c;
+        image_ptr->data = (float *)calloc((size_t)h * w * c, sizeof(float));
+        if (!image_ptr->data) throw std::runtime_error("mat_to_image: out of memory");
+        for (int k = 0; k < c; ++k) {
+            const int plane = (c >= 3 && k < 3) ? 2 - k : k;       // BGR -> RGB
+            for (int y = 0; y < h; ++y) {
+                const unsigned char *row = img.ptr<unsigned char>(y);
+                float *dst = image_ptr->data + ((size_t)plane * h + y) * w;
+                for (int x = 0; x < w; ++x) dst[x] = (float)(row[x * c + k] / 255.);
+            }
+        }
+        return image_ptr;
     }
 #endif
 

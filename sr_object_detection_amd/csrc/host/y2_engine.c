@@ -24,12 +24,23 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 #include "y2_internal.h"
 
 #define HIPCALL(expr) do { int rc_ = (expr); if (rc_ != 0) { y2_fail("%s failed (%d): %s", #expr, rc_, y2h_last_error()); return -1; } } while (0)
 
 static y2_ldev *ld_of(const layer *l) { return (y2_ldev *)l->dev; }
+
+static void drop_graphs(y2_engine *e)
+{
+    int k;
+    for (k = 0; k < 4; ++k) {
+        if (e->graphs[k]) y2h_graph_destroy(e->graphs[k]);
+        e->graphs[k] = NULL; e->graph_srcs[k] = NULL;
+    }
+    e->graph = NULL; e->graph_src = NULL; e->graph_next = 0;
+}
 
 y2_engine *y2_engine_of(const network *net) { return net ? (y2_engine *)net->engine : NULL; }
 
@@ -74,9 +85,14 @@ void y2_engine_host_output(network *net)
     ol = &net->layers[e->out_layer];
     need = (size_t)net->batch * ol->outputs;
     if (need > e->h_out_cap || !e->h_out) {
-        free(e->h_out);
-        e->h_out = NULL;
-        if (posix_memalign((void **)&e->h_out, 4096, (need ? need : 1) * sizeof(float)) != 0) e->h_out = NULL;
+        if (e->h_out_pinned) y2h_host_free(e->h_out); else free(e->h_out);
+        e->h_out = NULL; e->h_out_pinned = 0;
+        /* With a GPU in the machine the buffer is pinned memory of its own (hipHostMalloc, never a registered heap block:
+         * profiles/r02_notes.md), so that network_predict's device-to-host copy lands in the buffer the caller reads --
+         * one copy, as the reference's cuda_pull_array into l.output (network_kernels.cu:412-416).  Without one (cfg tools,
+         * the CPU test suite) it is plain page-aligned memory; nothing can be predicted then anyway. */
+        if (y2h_device_count() > 0 && y2h_host_alloc((void **)&e->h_out, (need ? need : 1) * sizeof(float)) == 0) e->h_out_pinned = 1;
+        else if (posix_memalign((void **)&e->h_out, 4096, (need ? need : 1) * sizeof(float)) != 0) e->h_out = NULL;
         if (e->h_out) memset(e->h_out, 0, (need ? need : 1) * sizeof(float));
         e->h_out_cap = need;
     }
@@ -101,7 +117,7 @@ static void free_plan(network *net)
         d->out_half = 0;
         d->tile_bm = d->tile_bn = d->ksplit = 0;
     }
-    if (e->graph) { y2h_graph_destroy(e->graph); e->graph = NULL; e->graph_src = NULL; }
+    drop_graphs(e);
     y2h_free(e->d_in_nchw); e->d_in_nchw = NULL;
     y2h_free(e->d_in_nhwc); e->d_in_nhwc = NULL;
     y2h_free(e->d_out_nchw); e->d_out_nchw = NULL;
@@ -146,11 +162,11 @@ void y2_engine_destroy(network *net)
     }
     y2h_free(e->arena);
     y2h_host_free(e->h_out_stage);
-    free(e->h_out);
+    if (e->h_out_pinned) y2h_host_free(e->h_out); else free(e->h_out);
     if (e->ev) { for (i = 0; i < e->n_ev; ++i) y2h_event_destroy(e->ev[i]); free(e->ev); }
     if (e->ev_det) y2h_event_destroy(e->ev_det);
     if (e->ev_out) y2h_event_destroy(e->ev_out);
-    if (e->graph) y2h_graph_destroy(e->graph);
+    drop_graphs(e);
     if (e->det_stream) y2h_stream_destroy(e->det_stream);
     if (e->ev_fwd) y2h_event_destroy(e->ev_fwd);
     y2h_stream_destroy(e->stream);
@@ -453,6 +469,7 @@ static int size_workspace(network *net)
 typedef struct { int batch, h, w, c, n, size, stride, pool, bm, bn, ks; } tune_entry;
 static tune_entry g_tuned[256];
 static int g_ntuned = 0;
+static pthread_mutex_t g_tuned_mu = PTHREAD_MUTEX_INITIALIZER;    /* networks / Detectors may be built from several threads */
 
 static int enqueue_forward(network *net, const float *d_input_nchw);
 
@@ -484,8 +501,8 @@ static int autotune_layers(network *net)
         HIPCALL(y2h_malloc((void **)&e->d_ws, need));
         e->ws_bytes = need;
     }
+    if (y2h_memset(e->d_in_nchw, 0, e->in_floats * sizeof(float), e->stream) != 0) { y2_fail("autotune: %s", y2h_last_error()); return -1; }
     e->timing = 1;
-    HIPCALL(y2h_memset(e->d_in_nchw, 0, e->in_floats * sizeof(float), e->stream));
     for (i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];
         y2_ldev *d = ld_of(l);
@@ -495,11 +512,13 @@ static int autotune_layers(network *net)
         if (l->type != CONVOLUTIONAL || !d->uses_mfma || l->xnor) continue;
         input_view(net, i, &x, &ldx);
         conv_desc(net, i, &c, x, ldx);
+        pthread_mutex_lock(&g_tuned_mu);
         for (k = 0; k < g_ntuned && !hit; ++k) {
             const tune_entry *t = &g_tuned[k];
             if (t->batch == c.batch && t->h == c.h && t->w == c.w && t->c == c.c && t->n == c.n && t->size == c.size &&
                 t->stride == c.stride && t->pool == c.fuse_maxpool2) { d->tile_bm = t->bm; d->tile_bn = t->bn; d->ksplit = t->ks; hit = 1; }
         }
+        pthread_mutex_unlock(&g_tuned_mu);
         /* big grids (hundreds of tiles per CU round) are where the cost model is reliable and a measurement costly */
         if (!hit && 2.0 * l->batch * l->out_h * l->out_w * (double)l->n * l->size * l->size * l->c > 40e9) continue;
         if (!hit) {
@@ -520,11 +539,13 @@ static int autotune_layers(network *net)
                 if (a == 0 || ms < best_ms) { best_ms = ms; best = a; }
             }
             d->tile_bm = bm[best]; d->tile_bn = bn[best]; d->ksplit = ks[best];
+            pthread_mutex_lock(&g_tuned_mu);
             if (g_ntuned < (int)(sizeof g_tuned / sizeof g_tuned[0])) {
                 tune_entry *t = &g_tuned[g_ntuned++];
                 t->batch = c.batch; t->h = c.h; t->w = c.w; t->c = c.c; t->n = c.n; t->size = c.size; t->stride = c.stride;
                 t->pool = c.fuse_maxpool2; t->bm = d->tile_bm; t->bn = d->tile_bn; t->ks = d->ksplit;
             }
+            pthread_mutex_unlock(&g_tuned_mu);
         }
         conv_desc(net, i, &c, x, ldx);
         d->kernel = y2h_conv_variant(&c, 0);
@@ -534,6 +555,12 @@ static int autotune_layers(network *net)
     HIPCALL(y2h_stream_sync(e->stream));
     return 0;
 }
+
+/* A replica (y2_weights_arena on a rank that never loads weights) is planned while its arena is still uninitialised HBM:
+ * timing candidates on garbage / NaN data would let every rank keep a different K-split, and ranks that are supposed to be
+ * bit-identical replicas would differ in the last bits.  Such a build keeps the cost model's choices; the measurement runs
+ * at the first build AFTER the arena became resident (y2_weights_resident drops the plan when autotuning is on). */
+static int autotune_allowed(const y2_engine *e) { return e->autotune && !e->strict && !e->arena_pending; }
 
 int y2_engine_build(network *net)
 {
@@ -964,9 +991,10 @@ int y2_engine_build(network *net)
     e->built_batch = net->batch; e->built_w = net->w; e->built_h = net->h; e->built_strict = e->strict;
     e->built_fusion = e->fusion;
     e->built_half = e->half;
-    e->built_autotune = e->autotune;
+    if (!e->weights_external) e->arena_pending = 0;              /* an ordinary build uploads the host weights below */
+    e->built_autotune = e->arena_pending ? 0 : e->autotune;      /* a skipped measurement is made up for at the next forward */
     if (e->weights_dirty && !e->weights_external && upload_weights(net) != 0) return -1;
-    if (e->autotune && !e->strict) {
+    if (autotune_allowed(e)) {
         /* measured tile shapes: needs the buffers and the arena, so it runs last; the scratch is sized again afterwards */
         if (autotune_layers(net) != 0 || size_workspace(net) != 0) { e->built = 0; return -1; }
     }
@@ -1012,14 +1040,27 @@ int y2_engine_forward(network *net, const float *d_input_nchw)
      * wait in front of the region layer, and the captured sequence itself carries no wait (e->capturing). */
     if (e->det_overlap && e->det_pending == 1 && e->ev_det) HIPCALL(y2h_stream_wait_event(e->stream, e->ev_det));
     if (!e->graph || e->graph_src != d_input_nchw) {
-        if (e->graph) { y2h_graph_destroy(e->graph); e->graph = NULL; }
-        HIPCALL(y2h_graph_begin(e->stream));
-        e->capturing = 1;
-        if (enqueue_forward(net, d_input_nchw) != 0) { e->capturing = 0; y2h_graph_abort(e->stream); return -1; }
-        e->capturing = 0;
-        if (y2h_graph_end(e->stream, &e->graph) != 0) { e->graph = NULL; y2_fail("hipGraph capture of the forward pass failed: %s", y2h_last_error()); return -1; }
+        /* one recording per input pointer, up to four (y2_feed_forward alternates between its HBM slots: with a single
+         * recording every step of a double-buffered feed would capture and instantiate again) */
+        int k, slot = -1;
+        for (k = 0; k < 4; ++k) if (e->graphs[k] && e->graph_srcs[k] == d_input_nchw) slot = k;
+        if (slot < 0) {
+            y2h_graph g = NULL;
+            slot = e->graph_next;
+            e->graph_next = (e->graph_next + 1) & 3;
+            if (e->graphs[slot]) { y2h_graph_destroy(e->graphs[slot]); e->graphs[slot] = NULL; e->graph_srcs[slot] = NULL; }
+            e->graph = NULL; e->graph_src = NULL;
+            HIPCALL(y2h_graph_begin(e->stream));
+            e->capturing = 1;
+            if (enqueue_forward(net, d_input_nchw) != 0) { e->capturing = 0; y2h_graph_abort(e->stream); return -1; }
+            e->capturing = 0;
+            if (y2h_graph_end(e->stream, &g) != 0) { y2_fail("hipGraph capture of the forward pass failed: %s", y2h_last_error()); return -1; }
+            e->graphs[slot] = g; e->graph_srcs[slot] = d_input_nchw;
+        }
+        e->graph = e->graphs[slot];
         e->graph_src = d_input_nchw;
     }
+    e->cur_input = d_input_nchw;
     HIPCALL(y2h_graph_launch(e->graph, e->stream));
     return 0;
 }
@@ -1199,6 +1240,11 @@ int y2_engine_fetch_output(network *net)
             HIPCALL(y2h_nhwc_to_nchw(d->out, d->out_ld, e->d_out_nchw, l->batch, l->out_c, l->out_h, l->out_w, e->stream));
         src = e->d_out_nchw;
     }
+    if (e->h_out_pinned) {          /* the synchronous call: straight into the caller's buffer */
+        HIPCALL(y2h_memcpy_d2h(e->h_out, src, e->out_floats * sizeof(float), e->stream));
+        HIPCALL(y2h_stream_sync(e->stream));
+        return 0;
+    }
     HIPCALL(y2h_memcpy_d2h(e->h_out_stage, src, e->out_floats * sizeof(float), e->stream));
     HIPCALL(y2h_stream_sync(e->stream));
     memcpy(e->h_out, e->h_out_stage, e->out_floats * sizeof(float));
@@ -1314,7 +1360,7 @@ void y2_set_graph(network *net, int on)
     y2_engine *e = y2_engine_of(net);
     if (!e) return;
     e->graph_on = on ? 1 : 0;
-    if (!on && e->graph) { y2h_graph_destroy(e->graph); e->graph = NULL; e->graph_src = NULL; }
+    if (!on) drop_graphs(e);
 }
 
 void y2_set_timing(network *net, int on)
@@ -1351,7 +1397,8 @@ int y2_weights_arena(network *net, void **dev_ptr, size_t *bytes)
         e->built_batch != net->batch || e->built_w != net->w || e->built_h != net->h) {
         /* (re-)requesting the arena: whatever layout it had before no longer binds */
         e->weights_external = 1; e->arena_sig = 0;
-        if (y2_engine_build(net) != 0) { e->weights_external = 0; return -1; }
+        e->arena_pending = 1;                /* this build uploads nothing: the arena is uninitialised HBM until it is filled from outside */
+        if (y2_engine_build(net) != 0) { e->weights_external = 0; e->arena_pending = 0; return -1; }
         e->weights_external = 0; e->weights_dirty = keep;
     }
     if (dev_ptr) *dev_ptr = e->arena;
@@ -1362,7 +1409,7 @@ int y2_weights_arena(network *net, void **dev_ptr, size_t *bytes)
 void y2_weights_resident(network *net)
 {
     y2_engine *e = y2_engine_of(net);
-    if (e) { e->weights_external = 1; e->weights_dirty = 0; }
+    if (e) { e->weights_external = 1; e->weights_dirty = 0; e->arena_pending = 0; }
 }
 
 void *y2_stream(network net) { y2_engine *e = y2_engine_of(&net); return e ? e->stream : NULL; }

@@ -54,6 +54,12 @@ int y2_feed_open(network *net, int slots, size_t slot_bytes)
     e->feed_host = calloc(slots, sizeof(void *)); e->feed_dev = calloc(slots, sizeof(void *));
     e->feed_up = calloc(slots, sizeof(y2h_event)); e->feed_done = calloc(slots, sizeof(y2h_event));
     e->feed_used = calloc(slots, sizeof(int));
+    if (!e->feed_host || !e->feed_dev || !e->feed_up || !e->feed_done || !e->feed_used) {
+        free(e->feed_host); free(e->feed_dev); free(e->feed_up); free(e->feed_done); free(e->feed_used);
+        e->feed_host = e->feed_dev = NULL; e->feed_up = e->feed_done = NULL; e->feed_used = NULL;
+        y2_fail("y2_feed_open: out of memory");
+        return -1;
+    }
     e->feed_slots = slots; e->feed_bytes = slot_bytes;
     HIPCALL_I(y2h_stream_create(&e->feed_stream));
     for (i = 0; i < slots; ++i) {

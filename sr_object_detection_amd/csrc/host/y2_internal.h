@@ -67,8 +67,11 @@ typedef struct y2_engine {
     y2h_event ev_fwd;          /* recorded on `stream` behind the forward pass whose region output the detect chain reads */
     int det_pending;           /* 1: wait for ev_det in y2_detect_fetch, 2: already fetched synchronously */
     int graph_on;
-    y2h_graph graph;
+    y2h_graph graph;           /* the graph in use (one of graphs[]) */
     const float *graph_src;
+    y2h_graph graphs[4];       /* recorded forward passes by input pointer (a double-buffered feed alternates between two) */
+    const float *graph_srcs[4];
+    int graph_next;            /* slot the next recording replaces */
     /* plan state */
     int built;
     int built_batch, built_w, built_h, built_strict;
@@ -77,6 +80,7 @@ typedef struct y2_engine {
     /* weight arena */
     unsigned char *arena;
     size_t arena_bytes;
+    int arena_pending;         /* the arena was laid out for a fill from outside (y2_weights_arena) that has not happened yet */
     int capturing;             /* inside the hipGraph capture of a forward pass (no cross-stream waits may be recorded) */
     uint64_t arena_sig;        /* hash of the per-layer offsets / forms the arena was laid out with (0: none yet) */
     /* io buffers */
@@ -92,8 +96,10 @@ typedef struct y2_engine {
                                   l.output (callers copy `layer` structs early), pinned once a GPU is in use */
     size_t out_floats;
     size_t h_out_cap;          /* floats allocated behind h_out */
-    float *h_out_stage;        /* pinned (hipHostMalloc) landing buffer of the output copy, out_floats long; h_out itself is
-                                  plain heap memory and is never handed to the GPU: registering it in place
+    int h_out_pinned;          /* h_out came from hipHostMalloc (a GPU was present at parse time): predict copies straight into it */
+    float *h_out_stage;        /* pinned (hipHostMalloc) landing buffer of the PIPELINED output copy (y2_output_enqueue / _fetch: the
+                                  caller may still read h_out while the next copy flies) and of hosts without pinned h_out;
+                                  heap memory is never handed to the GPU: registering h_out in place
                                   (hipHostRegister) made the runtime treat a pageable buffer that starts in the page behind
                                   it as part of the registration -- the next weight upload from such a buffer faulted */
     size_t h_out_stage_cap;

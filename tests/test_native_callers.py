@@ -27,6 +27,12 @@ def test_native_callers_compile_and_link(workdir):
     """No GPU needed: the reference-style callers build against our headers and resolve every symbol."""
     build(workdir, "kinect_like", "gcc", "kinect_like.c")
     build(workdir, "detector_cpp", "g++", "detector_cpp.cpp", ["-std=c++11"])
+    # the OPENCV surface of yolo_v2_class.hpp (detect(cv::Mat), detect_resized, mat_to_image_resize, mat_to_image) against
+    # a stand-in <opencv2/opencv.hpp>: the calls of yolo_console_dll.cpp:137,148 compile and link
+    build(workdir, "console_dll_like", "g++", "console_dll_like.cpp", OPENCV_FLAGS)
+
+
+OPENCV_FLAGS = ["-std=c++11", "-DOPENCV", "-I", os.path.join(SRC, "opencv_stub")]
 
 
 def write_frame(path, chw):
@@ -84,3 +90,24 @@ def test_cpp_detector_matches_oracle(oracle, workdir):
     assert any(l.startswith("THROW file not found") for l in lines)
     mean = [l for l in lines if l.startswith("MEAN")][0].split()
     assert int(mean[3]) == len(want)         # third use_mean call: the average of three identical frames
+
+
+@pytest.mark.gpu
+def test_console_dll_style_opencv_calls(workdir):
+    """yolo_console_dll.cpp:137,148: mat_to_image_resize (8-bit BGR frame -> planar RGB floats, v / 255.) followed by
+    detect_resized equals detect(image_t) on the same pixels; detect(cv::Mat) on a frame of twice the size returns the same
+    objects with boxes in the frame's pixels; an empty Mat throws as the reference does (yolo_v2_class.hpp:59-92)"""
+    g = load_golden("yolo_416_b1")
+    cfg, wts, x = materialize(workdir, "yolo", 416, 1, int(g["seed"]), float(g["head_gain"]))
+    frame = os.path.join(workdir, "frame416c.bin")
+    write_frame(frame, x[0])
+    exe = build(workdir, "console_dll_like", "g++", "console_dll_like.cpp", OPENCV_FLAGS)
+    out = subprocess.run([exe, cfg, wts, frame, repr(float(g["thresh"]))], capture_output=True, text=True, timeout=300, check=True).stdout
+    lines = out.strip().splitlines()
+    assert "IMAGE 1" in lines
+    resized = [l for l in lines if l.startswith("RESIZED")][0].split()
+    assert resized[1] == "1" and int(resized[2]) > 0
+    mat = [l for l in lines if l.startswith("MAT")][0].split()
+    assert mat[1] == "1" and int(mat[2]) == int(resized[2])
+    assert any(l.startswith("TRACKED %s" % resized[2]) for l in lines)
+    assert "THROW Image is empty" in lines
