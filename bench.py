@@ -85,6 +85,9 @@ def parse_args():
                          "decode kernels just queue between the persistent conv grids)")
     ap.add_argument("--autotune", type=int, default=0,
                     help="1: the plan measures the conv tile shapes once instead of modelling them (y2_set_autotune)")
+    ap.add_argument("--latency-iters", type=int, default=200,
+                    help="calls per entry of the batch-1 latency block (test_detector_img / Detector::detect on tiny-yolo-voc and "
+                         "yolo at 416; N=1 only; 0 disables)")
     ap.add_argument("--dump-dets", default=None, help="write each rank's last-batch detections to PATH.rank<r>.npz")
     return ap.parse_args()
 
@@ -311,6 +314,58 @@ def equivalence_vs_cpu(tmp: str, name: str, size: int, wts: str, x, gpu_dets, nf
     return dict(value=None if np.isnan(m) else round(m, 4), iou=0.5, frames=nframes, cpu_detections=n_ref, gpu_detections=n_gpu,
                 post_nms_counts_equal=bool(counts_equal), frames_with_a_different_set=mismatched,
                 max_abs_box_err=max_box, max_abs_prob_err=max_prob, tolerance=1e-4, kind=kind)
+
+
+def latency_block(tmp, seed, iters=200):
+    """Batch-1 latency of the reference's REAL callers, frame in host memory -> objects in host memory, per call:
+      * test_detector_img (detector.c:558-598, what KinectUtil.cpp:403 calls per camera frame): resize_image to the network
+        size, network_predict, get_region_boxes, do_nms_sort(0.1), object[] -- with a network-sized frame and with a 640x480
+        camera frame (device-side resize);
+      * Detector::detect(image_t) (yolo_v2_class.cpp:173-249), through the class's C face;
+      * the device part alone (frame already in HBM: forward + decode + NMS + fetch), for the gap between the two.
+    tiny-yolo-voc 416 (the robot's net) and yolo 416, p50 / p95 of `iters` back-to-back calls after 20 warm-up calls."""
+    import numpy as np
+    import torch
+    from sr_object_detection_amd import darknet, synth, zoo
+
+    def pcts(fn):
+        for _ in range(20):
+            fn()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts = np.sort(np.asarray(ts)) * 1e3
+        return dict(p50_ms=round(float(ts[len(ts) // 2]), 4), p95_ms=round(float(ts[int(len(ts) * 0.95)]), 4))
+
+    out = dict(iters=iters, batch=1, frame="416x416x3 float planes in host memory (and 640x480x3 for the camera-sized call)",
+               thresh=0.24, nms=0.1, nets={})
+    cam = synth.image_batch(1, 3, 480, 640, seed=3)[0]
+    for name in ("tiny-yolo-voc", "yolo"):
+        cfg = write_cfg(tmp, name, 416, 1, "lat_%s.cfg" % name.replace("-", "_"))
+        wts = os.path.join(tmp, "lat_%s.weights" % name.replace("-", "_"))
+        synth.write_weights(wts, zoo.resolve(name, 416), seed)
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        x = synth.image_batch(1, 3, 416, 416)
+        d_x = torch.from_numpy(x).cuda()
+        det = darknet.Detector(cfg, wts, 0)
+        r = {
+            "test_detector_img": pcts(lambda: net.test_detector_img(x[0], 0.24)),
+            "test_detector_img_640x480": pcts(lambda: net.test_detector_img(cam, 0.24)),
+            "Detector_detect": pcts(lambda: det.detect(x[0], 0.24, False, 0.1)),
+            "device_only": pcts(lambda: (net.forward_device(d_x.data_ptr()), net.detect_resident(0.24, 0.1))),
+        }
+        net.set_timing(True)
+        net.forward_device(d_x.data_ptr())
+        net.detect_resident(0.24, 0.1)
+        r["forward_kernels_ms"] = round(float(np.sum(net.layer_times_ms())), 4)      # HIP events around every layer of one forward
+        r["objects"] = len(net.test_detector_img(x[0], 0.24))
+        out["nets"][name + " 416x416"] = r
+        det.free()
+        net.free()
+    return out
 
 
 def main():
@@ -644,6 +699,7 @@ def main():
         equiv = None
         if world == 1 and args.cpu_iters > 0 and is_detector and args.equiv_frames > 0:
             equiv = equivalence_vs_cpu(tmp, name, size, wts, x, dets, args.equiv_frames)
+        latency = latency_block(tmp, args.seed, args.latency_iters) if (world == 1 and args.latency_iters > 0) else None
         what = ("forward + region decode + NMS(%.1f) + collect + fetch of the detections" % NMS) if is_detector else \
                "forward (conv trunk, avgpool, softmax) + fetch of the class scores"
         line = {
@@ -665,7 +721,7 @@ def main():
                        "conv_tflops": round(conv_flops_step / (conv_ms * 1e-3) / 1e12, 2) if conv_ms else None,
                        "host_fetch_overlaps_next_forward": True,
                        "detections_in_last_batch": int(np.sum(counts))},
-            "roofline": roof, "cpu_baseline": cpu, "host_input": host, "map_equiv_vs_cpu": equiv,
+            "roofline": roof, "cpu_baseline": cpu, "host_input": host, "map_equiv_vs_cpu": equiv, "latency": latency,
             "kernels_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in sorted(per_kernel_ms.items())},
             "device": darknet.device_name(),
         }

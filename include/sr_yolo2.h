@@ -314,6 +314,16 @@ int y2_comm_count(void *comm, int *nranks, int *rank);
  * ranks before it moves a byte (RCCL itself checks neither counts nor types); a launcher that replicates the arena by
  * other means must do the same. */
 int y2_weights_layout(network *net, unsigned long long *signature, size_t *bytes);
+/* C face of the C++ Detector class (include/yolo_v2_class.hpp) for FFI callers that cannot bind a C++ class (ctypes, cgo,
+ * JNI).  y2_detector_detect = Detector::detect(image_t) [+ Detector::tracking when track != 0]: `chw` is a planar float
+ * image in [0,1], up to `max` results are written to `out` in bbox_t's own layout (4 unsigned, float, 2 unsigned = 28
+ * bytes each); returns the number of boxes (may exceed max) or < 0 with the message in y2_last_error().  nms < 0 keeps
+ * the detector's current Detector::nms. */
+void *y2_detector_create(const char *cfg, const char *weights, int gpu_id);
+void  y2_detector_destroy(void *det);
+int   y2_detector_net_size(void *det, int *w, int *h);
+int   y2_detector_detect(void *det, const float *chw, int c, int h, int w, float thresh, int use_mean, float nms, int track,
+                         void *out, int max);
 /* Pinned, multi-buffered host feed (replaces the per-call cudaMalloc + pageable H2D + cudaFree of
  * network_kernels.cu:392-405): `slots` pairs of (pinned host buffer, HBM buffer) of slot_bytes each (0 = one batch of
  * float NCHW frames) and a copy stream.  The producer writes a batch into y2_feed_host(net, s), y2_feed_submit starts

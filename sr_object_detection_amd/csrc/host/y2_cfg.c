@@ -51,6 +51,13 @@ void y2_fail(const char *fmt, ...)
     }
 }
 
+/* record a message without ever leaving the process (the C face of the C++ Detector turns exceptions into return codes) */
+void y2_set_error_(const char *msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg ? msg : "");
+    g_flag = 1;
+}
+
 /* for bindings: did the last legacy call fail (and reset the flag); struct sizes for layout checks */
 int y2_failed_and_clear(void) { return y2_failed(); }
 size_t y2_sizeof_layer(void) { return sizeof(layer); }

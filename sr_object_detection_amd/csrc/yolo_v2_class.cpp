@@ -222,3 +222,44 @@ std::vector<bbox_t> Detector::tracking(std::vector<bbox_t> cur, int const frames
     remember();
     return cur;
 }
+
+// ---------------------------------------------------------------------------
+// C face of the Detector class for FFI callers (ctypes, cgo, JNI: languages that cannot bind a C++ class).  Plain
+// pointers and sizes; an exception becomes a negative return and a message in y2_last_error().  Declared in
+// include/sr_yolo2.h.  (The reference exports only the C++ class from its DLL, yolo_v2_class.hpp:42-57.)
+// ---------------------------------------------------------------------------
+extern "C" void y2_set_error_(const char *msg);
+
+extern "C" void *y2_detector_create(const char *cfg, const char *weights, int gpu_id)
+{
+    try { return new Detector(cfg ? cfg : "", weights ? weights : "", gpu_id); }
+    catch (const std::exception &e) { y2_set_error_(e.what()); return nullptr; }
+}
+
+extern "C" void y2_detector_destroy(void *det) { delete static_cast<Detector *>(det); }
+
+extern "C" int y2_detector_net_size(void *det, int *w, int *h)
+{
+    if (!det) return -1;
+    if (w) *w = static_cast<Detector *>(det)->get_net_width();
+    if (h) *h = static_cast<Detector *>(det)->get_net_height();
+    return 0;
+}
+
+// detect(image_t) (+ tracking when track != 0): up to `max` boxes are written to out[] as 7 unsigned / float words each in
+// bbox_t's own layout; returns the number of boxes found (which may exceed max) or < 0
+extern "C" int y2_detector_detect(void *det, const float *chw, int c, int h, int w, float thresh, int use_mean, float nms,
+                                  int track, void *out, int max)
+{
+    if (!det || !chw) { y2_set_error_("y2_detector_detect: NULL detector or image"); return -1; }
+    try {
+        Detector *d = static_cast<Detector *>(det);
+        if (nms >= 0.f) d->nms = nms;
+        image_t im; im.c = c; im.h = h; im.w = w; im.data = const_cast<float *>(chw);
+        std::vector<bbox_t> r = d->detect(im, thresh, use_mean != 0);
+        if (track) r = d->tracking(r);
+        const int n = (int)r.size();
+        if (out && max > 0) std::memcpy(out, r.data(), sizeof(bbox_t) * (size_t)std::min(n, max));
+        return n;
+    } catch (const std::exception &e) { y2_set_error_(e.what()); return -1; }
+}

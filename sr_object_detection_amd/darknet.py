@@ -200,6 +200,12 @@ def lib():
     L.y2_comm_destroy.argtypes = [C.c_void_p]
     L.y2_broadcast_weights.argtypes = [C.POINTER(CNetwork), C.c_void_p, C.c_int]
     L.y2_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.y2_detector_create.restype = C.c_void_p
+    L.y2_detector_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    L.y2_detector_destroy.argtypes = [C.c_void_p]
+    L.y2_detector_net_size.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.y2_detector_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int,
+                                     C.c_void_p, C.c_int]
     L.y2_weights_layout.argtypes = [C.POINTER(CNetwork), C.POINTER(C.c_ulonglong), C.POINTER(C.c_size_t)]
     L.y2_network_predict_device.restype = C.POINTER(C.c_float)
     L.y2_network_predict_device.argtypes = [CNetwork, C.c_void_p]
@@ -750,6 +756,40 @@ def letterbox_image(im: np.ndarray, w: int, h: int, into: np.ndarray | None = No
     if failed:
         raise Y2Error("letterbox_image: " + _check())
     return arr
+
+
+BBOX_DTYPE = np.dtype([("x", "<u4"), ("y", "<u4"), ("w", "<u4"), ("h", "<u4"), ("prob", "<f4"), ("obj_id", "<u4"), ("track_id", "<u4")])
+
+
+class Detector:
+    """The C++ Detector class (include/yolo_v2_class.hpp; reference yolo_v2_class.hpp:42-57) through its C face."""
+
+    def __init__(self, cfg: str, weights: str = "", gpu: int = 0):
+        lib().y2_set_error_mode(1)
+        self.h = lib().y2_detector_create(cfg.encode(), weights.encode(), gpu)
+        if not self.h:
+            raise Y2Error("Detector: " + _check())
+        self._out = np.zeros(4096, dtype=BBOX_DTYPE)
+
+    def net_size(self):
+        w, h = C.c_int(0), C.c_int(0)
+        lib().y2_detector_net_size(C.c_void_p(self.h), C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def detect(self, chw: np.ndarray, thresh: float = 0.2, use_mean: bool = False, nms: float = -1.0, track: bool = False) -> np.ndarray:
+        """Detector::detect(image_t) (+ tracking): structured array of bbox_t"""
+        chw = np.ascontiguousarray(chw, dtype=np.float32)
+        c, h, w = chw.shape
+        n = lib().y2_detector_detect(C.c_void_p(self.h), _ptr(chw), c, h, w, thresh, int(use_mean), nms, int(track),
+                                     _ptr(self._out), self._out.size)
+        if n < 0:
+            raise Y2Error("Detector.detect: " + _check())
+        return self._out[:min(n, self._out.size)].copy()
+
+    def free(self) -> None:
+        if self.h:
+            lib().y2_detector_destroy(C.c_void_p(self.h))
+            self.h = None
 
 
 def comm_unique_id() -> bytes:

@@ -133,6 +133,21 @@ def test_f16_tile_is_exact(oracle, workdir, monkeypatch, tile, bk, ksize, pool):
 
 
 @pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("ksize", [1, 3])
+@pytest.mark.parametrize("bk", [64, 32])
+def test_f16_register_staged_256x256_m16_is_exact(oracle, workdir, monkeypatch, bk, ksize, pool):
+    """the register-staged 16x16x32 form of the 256x256 tile (conv_mfma_f16_kernel<256, 256, ..., M16 = true>): what runs
+    when the LDS-DMA kernel is switched off (Y2_F16_NO_P8, the A/B switch of profiles/r02_notes.md) and, at BK = 32, the
+    only 16x16x32 form there is"""
+    monkeypatch.setenv("Y2_F16_NO_P8", "1")
+    out, ref, name, l0 = _run(oracle, workdir, monkeypatch, cin=64 if bk == 64 else 96, filters=296, ksize=ksize, size=26, batch=2,
+                              tile=(256, 256), pool=pool, half=True, seed=33000 + bk + ksize * 100 + pool * 1000)
+    assert name == "conv_mfma_f16_256x256x%d_k%d%s" % (bk, ksize, "+maxpool2" if pool else ""), name
+    assert l0 <= 2048 and np.abs(ref).max() < 60000
+    assert np.array_equal(out, _as_half(ref))
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
 @pytest.mark.parametrize("tile", [t for t in F16_TILES if not t[2]], ids=lambda t: "%dx%d" % (t[0], t[1]))
 def test_f16_tile_scalar_store_path_is_exact(oracle, workdir, monkeypatch, tile, pool):
     """a filter count that is not a multiple of 8 takes the 2-byte store epilogue"""
