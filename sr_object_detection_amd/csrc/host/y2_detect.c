@@ -315,9 +315,19 @@ static int detect_enqueue(network net, float *d_pred, float thresh, float nms, i
     q.tree_parent = l->softmax_tree ? d->d_tree_parent : NULL;
     q.tree_order = d->d_tree_order; q.tree_level_off = d->d_tree_loff; q.tree_levels = d->tree_levels;
     q.pred = d_pred; q.boxes = e->d_boxes; q.probs = e->d_probs;
+    if (y2h_detect_chain_ok(&q)) {
+        /* plain head: decode + NMS + compaction in three launches (the class counts stay zero between calls) */
+        if (!e->class_counts_zeroed) {
+            HIPCALL_I(y2h_memset(e->d_class_counts, 0, (size_t)net.batch * l->classes * sizeof(int), ds));
+            e->class_counts_zeroed = 1;
+        }
+        HIPCALL_I(y2h_detect_chain(&q, nms, e->d_probs_nms, e->d_class_counts, e->d_records, e->d_counts, e->det_cap, ds));
+        goto fetch;
+    }
     HIPCALL_I(y2h_region_boxes(&q, ds));
     }
     final_probs = e->d_probs;
+    e->class_counts_zeroed = 0;               /* y2h_nms_sort leaves its counts behind */
     if (nms > 0) {
         HIPCALL_I(y2h_memcpy_d2d(e->d_probs_nms, e->d_probs, (size_t)net.batch * e->det_total * l->classes * sizeof(float), ds));
         HIPCALL_I(y2h_nms_sort(e->d_boxes, e->d_probs, e->d_probs_nms, net.batch, e->det_total, l->classes, l->classes, nms, e->d_class_counts, ds));
@@ -325,6 +335,7 @@ static int detect_enqueue(network net, float *d_pred, float thresh, float nms, i
     }
     HIPCALL_I(y2h_collect(e->d_boxes, final_probs, net.batch, e->det_total, l->classes, l->classes, thresh,
                           e->d_records, e->d_counts, e->det_cap, e->d_best, ds));
+fetch:
     HIPCALL_I(y2h_memcpy_d2h(e->h_counts, e->d_counts, (size_t)net.batch * sizeof(int), ds));
     keep = 0;
     if ((size_t)net.batch * e->det_cap * 6 * sizeof(float) <= ((size_t)8 << 20)) {

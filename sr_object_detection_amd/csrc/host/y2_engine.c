@@ -837,6 +837,7 @@ int y2_engine_build(network *net)
             HIPCALL(y2h_malloc((void **)&e->d_records, (size_t)net->batch * e->det_cap * 6 * sizeof(float)));
             HIPCALL(y2h_malloc((void **)&e->d_counts, (size_t)net->batch * sizeof(int)));
             HIPCALL(y2h_malloc((void **)&e->d_class_counts, (size_t)net->batch * ol->classes * sizeof(int)));
+            e->class_counts_zeroed = 0;
             HIPCALL(y2h_malloc((void **)&e->d_best, (size_t)2 * net->batch * e->det_total * sizeof(float)));
             HIPCALL(y2h_host_alloc((void **)&e->h_records, (size_t)net->batch * e->det_cap * 6 * sizeof(float)));
             HIPCALL(y2h_host_alloc((void **)&e->h_counts, (size_t)net->batch * sizeof(int)));

@@ -81,6 +81,7 @@ typedef struct y2_engine {
     unsigned char *arena;
     size_t arena_bytes;
     int arena_pending;         /* the arena was laid out for a fill from outside (y2_weights_arena) that has not happened yet */
+    int class_counts_zeroed;   /* d_class_counts is all zero (the three-launch detect chain keeps it so) */
     int capturing;             /* inside the hipGraph capture of a forward pass (no cross-stream waits may be recorded) */
     uint64_t arena_sig;        /* hash of the per-layer offsets / forms the arena was laid out with (0: none yet) */
     /* io buffers */

@@ -10,6 +10,7 @@
 // bit-identical to the CPU path.
 #include "y2_common.hpp"
 #include <float.h>
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------
 // get_region_boxes (region_layer.c:328-379) + get_region_box (:73-85, DOABS=1)
@@ -256,9 +257,17 @@ __global__ __launch_bounds__(256) void class_count_kernel(const float *__restric
 #define NMS_LDS_BOXES 1024
 __global__ __launch_bounds__(256) void nms_sort_kernel(const float *__restrict__ boxes, const float *__restrict__ pin_all,
                                                        float *__restrict__ pout_all, const int *__restrict__ class_counts,
-                                                       int total, int classes, int stride, float thresh, int cap, int lds_boxes)
+                                                       int total, int classes, int stride, float thresh, int cap, int lds_boxes,
+                                                       int *__restrict__ reset_counts)
 {
-    if (class_counts[blockIdx.x] < 2) return;
+    // (the three-launch chain, y2h_detect_chain: this workgroup is the only reader of its count; it leaves the word zero for the
+    // next frame's decode kernel to add to -- every lane reads before lane 0 writes)
+    const int my_count = class_counts[blockIdx.x];
+    if (reset_counts) {
+        __syncthreads();
+        if (threadIdx.x == 0) reset_counts[blockIdx.x] = 0;
+    }
+    if (my_count < 2) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
     unsigned long long *keys = (unsigned long long *)nms_smem;          // [cap]
     unsigned char *dead = (unsigned char *)(keys + cap);                // [cap]
@@ -381,7 +390,7 @@ extern "C" int y2h_nms_sort(const float *boxes, const float *probs_in, float *pr
                        probs_in, class_counts, total, classes, stride, nel);
     Y2H_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)(batch * classes)), dim3(256), lds, S(s),
-                       boxes, probs_in, probs, class_counts, total, classes, stride, thresh, cap, lds_boxes);
+                       boxes, probs_in, probs, class_counts, total, classes, stride, thresh, cap, lds_boxes, (int *)nullptr);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }
@@ -526,6 +535,146 @@ extern "C" int y2h_collect(const float *boxes, const float *probs, int batch, in
     Y2H_LAUNCH_CHECK();
     hipLaunchKernelGGL(collect_kernel, dim3((unsigned)batch), dim3(256), 0, S(s),
                        boxes, best_val, best_cls, total, thresh, records, counts, max_per_image);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The detection chain of a plain region head in THREE launches instead of eight (batch 1, the robot's mode: every one of
+// decode_boxes / decode_probs / copy / memset / class_count / nms_sort / best_class / collect runs 4-6 us for 845 boxes x 20
+// classes, 60 us of a 250 us frame; profiles/r03_notes.md):
+//   decode_all_kernel   = decode_boxes_kernel + decode_probs_kernel + the copy of the scores NMS suppresses in + the
+//                         per-class candidate counts (which the NMS kernel zeroes again after reading them)
+//   nms_sort_kernel     unchanged
+//   best_collect_kernel = best_class_kernel + collect_kernel
+// Same expressions, same order, same results as the separate kernels (tests/test_gpu_kernels.py compares them).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_all_kernel(DecodeK d, float *__restrict__ probs2, int *__restrict__ class_counts)
+{
+    const long total = d.nboxes * d.classes;
+    const int size = d.classes + 5, per = d.w * d.h * d.num;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int j = (int)(idx % d.classes);
+        const long gi = idx / d.classes;
+        const float *x = d.pred + gi * size;
+        float scale = x[4];
+        if (d.classfix == -1 && scale < .5) scale = 0;
+        const float prob = scale * x[5 + j];
+        float v = (prob > d.thresh) ? prob : 0;
+        if (d.only_objectness && j == 0) v = scale;
+        d.probs[idx] = v;
+        if (probs2) {
+            probs2[idx] = v;
+            if (v != 0) atomicAdd(&class_counts[(gi / per) * d.classes + j], 1);
+        }
+        if (j == 0) {                                   // region_layer.c:73-85 get_region_box, as decode_boxes_kernel
+            const int index = (int)(gi % per);
+            const int n = index % d.num, cell = index / d.num;
+            const int row = cell / d.w, col = cell % d.w;
+            float bx = (col + logistic_f(x[0])) / d.w;
+            float by = (row + logistic_f(x[1])) / d.h;
+            float bw = (float)(exp((double)x[2]) * d.anchors[2 * n] / d.w);
+            float bh = (float)(exp((double)x[3]) * d.anchors[2 * n + 1] / d.h);
+            bx *= d.img_w; by *= d.img_h; bw *= d.img_w; bh *= d.img_h;
+            float *bo = d.boxes + gi * 4;
+            bo[0] = bx; bo[1] = by; bo[2] = bw; bo[3] = bh;
+        }
+    }
+}
+
+// one workgroup per image: each lane finds the best class of its box (utils.c:533 max_index: the FIRST maximum), then the
+// ordered compaction of collect_kernel
+__global__ __launch_bounds__(256) void best_collect_kernel(const float *__restrict__ boxes, const float *__restrict__ probs,
+                                                           int total, int classes, int stride, float thresh,
+                                                           float *__restrict__ records, int *__restrict__ counts, int max_per)
+{
+    __shared__ int s_scan[256];
+    __shared__ int s_base;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *bx = boxes + (size_t)b * total * 4;
+    const float *pr = probs + (size_t)b * total * stride;
+    float *rec = records + (size_t)b * max_per * 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < total; i0 += 256) {
+        const int i = i0 + t;
+        int cls = 0, keep = 0;
+        float best = 0;
+        if (i < total) {
+            const float *p = pr + (size_t)i * stride;
+            best = p[0];
+            for (int k = 1; k < classes; ++k) {
+                const float v = p[k];
+                if (v > best) { best = v; cls = k; }
+            }
+            keep = best > thresh;
+        }
+        s_scan[t] = keep;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = (t >= off) ? s_scan[t - off] : 0;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        const int pos = s_base + s_scan[t] - keep;
+        if (keep && pos < max_per) {
+            float *r = rec + (size_t)pos * 6;
+            r[0] = bx[(size_t)i * 4 + 0]; r[1] = bx[(size_t)i * 4 + 1];
+            r[2] = bx[(size_t)i * 4 + 2]; r[3] = bx[(size_t)i * 4 + 3];
+            r[4] = best; r[5] = (float)cls;
+        }
+        __syncthreads();
+        if (t == 255) s_base += s_scan[255];
+        __syncthreads();
+    }
+    if (t == 0) counts[b] = s_base;
+}
+
+extern "C" int y2h_detect_chain_ok(const y2h_decode *q)
+{
+    return q && !q->tree_parent && !q->map && q->classes <= 256 && (long)q->w * q->h * q->num <= 16384 && !getenv("Y2_DETECT_SEPARATE");
+}
+
+// decode + NMS (nms > 0) + compaction for a plain region head; `class_counts` (batch * classes ints) must be ZERO on entry
+// and is zero again on return (the NMS workgroups reset their own words)
+extern "C" int y2h_detect_chain(const y2h_decode *q, float nms, float *probs_nms, int *class_counts, float *records,
+                                int *counts, int max_per_image, y2h_stream s)
+{
+    if (!y2h_detect_chain_ok(q) || !q->pred || !q->boxes || !q->probs || !q->anchors || !records || !counts || max_per_image <= 0)
+        return Y2H_EINVAL;
+    if (nms > 0 && (!probs_nms || !class_counts)) return Y2H_EINVAL;
+    DecodeK d;
+    d.w = q->w; d.h = q->h; d.num = q->num; d.classes = q->classes; d.img_w = q->img_w; d.img_h = q->img_h;
+    d.thresh = q->thresh; d.only_objectness = q->only_objectness; d.classfix = q->classfix;
+    d.anchors = q->anchors; d.parent = nullptr; d.map = nullptr;
+    d.pred = q->pred; d.boxes = q->boxes; d.probs = q->probs;
+    d.nboxes = (long)q->batch * q->w * q->h * q->num;
+    d.tree_seq = 0;
+    const int total = q->w * q->h * q->num;
+    hipLaunchKernelGGL(decode_all_kernel, dim3(y2h_grid(d.nboxes * d.classes, 256)), dim3(256), 0, S(s), d,
+                       nms > 0 ? probs_nms : (float *)nullptr, class_counts);
+    Y2H_LAUNCH_CHECK();
+    const float *final_probs = q->probs;
+    if (nms > 0) {
+        int cap = 1;
+        while (cap < total) cap <<= 1;
+        const int lds_boxes = cap <= 8192 ? NMS_LDS_BOXES : 0;
+        const size_t lds = (((size_t)cap * 9 + 15) & ~(size_t)15) + (size_t)lds_boxes * 16;
+        static bool attr_set[16] = {false};
+        int dev = 0;
+        Y2H_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+            Y2H_CHECK(hipFuncSetAttribute((const void *)nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 9));
+            if (dev >= 0 && dev < 16) attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)(q->batch * q->classes)), dim3(256), lds, S(s),
+                           q->boxes, q->probs, probs_nms, class_counts, total, q->classes, q->classes, nms, cap, lds_boxes, class_counts);
+        Y2H_LAUNCH_CHECK();
+        final_probs = probs_nms;
+    }
+    hipLaunchKernelGGL(best_collect_kernel, dim3((unsigned)q->batch), dim3(256), 0, S(s), q->boxes, final_probs, total, q->classes,
+                       q->classes, q->thresh, records, counts, max_per_image);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }

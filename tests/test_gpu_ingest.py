@@ -335,3 +335,41 @@ def test_output_enqueue_fetch_matches_predict_device(workdir):
     with pytest.raises(darknet.Y2Error):
         net.output_fetch()
     net.free()
+
+
+@pytest.mark.parametrize("netname,size,batch,seed", [("tiny-yolo-voc", 416, 2, 21), ("yolo", 160, 4, 831), ("mini-mfma", 64, 3, 5)])
+def test_three_launch_detect_chain_equals_separate_kernels(workdir, monkeypatch, netname, size, batch, seed):
+    """y2h_detect_chain (decode_all + nms_sort + best_collect) against the eight separate launches it replaces
+    (Y2_DETECT_SEPARATE=1): identical records and counts, frame after frame (the per-class candidate counts must come back
+    to zero by themselves), with and without NMS, at two thresholds (region_layer.c:328-379, box.c:249-277,
+    yolo_v2_class.cpp:221-238)"""
+    import os
+    import torch
+    from sr_object_detection_amd import synth, zoo
+    cfg = os.path.join(workdir, "chain_%s.cfg" % netname)
+    open(cfg, "w").write(zoo.cfg_text(netname, size, size, batch))
+    wts = os.path.join(workdir, "chain_%s.weights" % netname)
+    synth.write_weights(wts, zoo.resolve(netname, size), seed)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    frames = [torch.from_numpy(synth.image_batch(batch, 3, size, size, seed=90 + i)).cuda() for i in range(4)]
+    results = {}
+    for mode in ("separate", "chain"):
+        if mode == "separate":
+            monkeypatch.setenv("Y2_DETECT_SEPARATE", "1")
+        else:
+            monkeypatch.delenv("Y2_DETECT_SEPARATE", raising=False)
+        got = []
+        for thresh, nms in ((0.2, 0.4), (0.05, 0.4), (0.2, 0.0), (0.1, 0.1)):
+            for f in frames:
+                net.forward_device(f.data_ptr())
+                got.append(net.detect_resident(thresh, nms))
+        results[mode] = got
+    total = 0
+    for (da, ca), (db, cb) in zip(results["separate"], results["chain"]):
+        assert np.array_equal(ca, cb)
+        total += int(ca.sum())
+        for a, b in zip(da, db):
+            assert np.array_equal(a, b)
+    assert total > 50
+    net.free()
