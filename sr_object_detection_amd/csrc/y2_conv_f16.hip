@@ -1115,6 +1115,191 @@ static int c32_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     return Y2H_OK;
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 convolution with 64 input channels and <= 128 filters (the 64 -> 128 layers at 112x112 of every Darknet-19 trunk:
+// 17 % of the darknet19_448 b128 step at 0.28-0.30 of the fp16 peak on the generic 256x128 tile, whose K loop stages every
+// input pixel nine times -- once per tap -- for only 128 filters of work).  Same plan as conv_c32_f16_kernel:
+//   * weights stationary in registers: a wave owns ONE 32-filter tile, 36 k-fragments (9 taps x 4 k-steps of 16 channels)
+//     = 144 VGPRs, two waves per SIMD; the eight waves of the one workgroup per CU are (filter tile fq, strip half sh):
+//     wave (fq, sh) computes filters 32 fq .. +31 of strips 4 sh .. 4 sh + 3.  (A first form with two filter tiles per wave
+//     -- 288 registers, one wave per SIMD, half the LDS reads -- ran at 34 % matrix-busy: with nobody to hide them every
+//     operand read was exposed, and at the 256-VGPR ceiling the compiler sinks each read next to its MFMAs whatever the
+//     source order says; profiles/r03_notes.md);
+//   * a workgroup walks 16x16-pixel output tiles; the 18x18-pixel input patch of the NEXT tile (128 B per pixel) is fetched
+//     into registers during the current tile's 144 MFMAs per wave and written to the other LDS buffer afterwards: every
+//     input pixel reaches the CU once per tile (1.27x with the halo) instead of nine times, one barrier per tile;
+//   * an MFMA row tile is a 2 x 16 pixel strip in pool-major order read straight from the patch with one ds_read_b128 per
+//     tap and k-step.  Pixel pitch 144 B and row pitch 2688 B (= 128 mod 256) make the 16-lane groups of a ds_read_b128
+//     hit sixteen distinct 16-byte slots: conflict free;
+//   * outputs leave as 16-byte stores through a wave-private LDS transpose, pooled (8 windows x 32 filters) or not
+//     (32 pixels x 32 filters).
+// ---------------------------------------------------------------------------
+template <bool POOL, bool LEAKY>
+__global__ __launch_bounds__(512, 2) void conv_c64_f16_kernel(ConvK a)
+{
+    const int ACT_ = LEAKY ? (int)Y2H_ACT_LEAKY : a.act;
+    constexpr int PW = 18, PIX_B = 144, ROW_B = 2688, BUF_B = PW * ROW_B;
+    constexpr int NCH = PW * PW * 8;                 // 16-byte chunks of one patch
+    constexpr int NP = (NCH + 511) / 512;            // staging passes
+    constexpr int ES_B = 80;                         // scratch row: 32 filters x 2 B + 16 B
+    extern __shared__ __attribute__((aligned(16))) unsigned char c64_smem[];
+    const int t = threadIdx.x, lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fq = wv & 3, sh = wv >> 2;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+
+    f16x8 bw[36];
+    const int co = 32 * fq + li;
+    const bool cok = co < a.Cout;
+    const float alpha = cok ? a.alpha[co] : 0.f, beta = cok ? a.beta[co] : 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 36; ++kk) {            // fragment kk = tap * 4 + k-step: K index tap * 64 + ks * 16 + 8 lh .. + 7
+        const unsigned off = cok ? (unsigned)((co * 576 + (kk >> 2) * 64 + (kk & 3) * 16 + 8 * lh) * 2) : a.wbytes;
+        bw[kk] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+    }
+
+    // staging role: chunk q = t + 512 p of the patch -> patch pixel (py, px), 16-byte part
+    const int ldxB = a.ldx * 2;
+    int s_lds[NP], s_rel[NP], s_yx[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int q = t + 512 * p;
+        const int pixel = q >> 3, part = q & 7;
+        const int py = pixel / PW, px = pixel - py * PW;
+        s_lds[p] = py * ROW_B + px * PIX_B + part * 16;
+        s_rel[p] = ((py - 1) * a.W + (px - 1)) * ldxB + part * 16;
+        s_yx[p] = q < NCH ? (py << 8) | px : -1;
+    }
+    const int tiles_x = a.W >> 4, tpi = (a.H >> 4) * tiles_x;
+    const int ntiles = a.batch * tpi;
+    u32x4 sreg[NP];
+    auto load_tile = [&](int tile) {
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int oy0 = (rem / tiles_x) << 4, ox0 = (rem - (rem / tiles_x) * tiles_x) << 4;
+        const int base = ((n * a.H + oy0) * a.W + ox0) * ldxB;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int iy = oy0 - 1 + (s_yx[p] >> 8), ix = ox0 - 1 + (s_yx[p] & 255);
+            const bool ok = s_yx[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            sreg[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)(base + s_rel[p]) : a.xbytes, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (s_yx[p] >= 0) *(u32x4 *)(c64_smem + buf * BUF_B + s_lds[p]) = sreg[p];
+    };
+
+    // this lane's pixel inside a 2 x 16 strip: window li>>2, corner li&3
+    const int a_off = ((li >> 1) & 1) * ROW_B + (2 * (li >> 2) + (li & 1)) * PIX_B + lh * 16;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    _Float16 *yh = (_Float16 *)a.y;
+    unsigned char *es = c64_smem + 2 * BUF_B + wv * 32 * ES_B;          // [32 rows][32 filters + pad], wave-private
+    const int cbase = 32 * fq + (lane & 3) * 8;                          // first of the 8 filters this lane stores
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile < ntiles) { load_tile(tile); store_tile(0); }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int oy0 = (rem / tiles_x) << 4, ox0 = (rem - (rem / tiles_x) * tiles_x) << 4;
+#pragma unroll
+        for (int rpi = 0; rpi < 4; ++rpi) {
+            const int rp = 4 * sh + rpi;                       // strip = output rows oy0 + 2 rp, + 1
+            const unsigned char *ap = c64_smem + cur * BUF_B + 2 * rp * ROW_B + a_off;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const f16x8 af = *(const f16x8 *)(ap + kh * ROW_B + kw * PIX_B + ks * 32);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bw[(kh * 3 + kw) * 4 + ks], acc, 0, 0, 0);
+                    }
+            if (POOL) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float m = epilogue_fast(acc[4 * g], alpha, beta, ACT_);
+#pragma unroll
+                    for (int u = 1; u < 4; ++u) m = __builtin_fmaxf(m, epilogue_fast(acc[4 * g + u], alpha, beta, ACT_));
+                    *(_Float16 *)(es + (2 * g + lh) * ES_B + li * 2) = (_Float16)m;
+                }
+                const u32x4 v = *(const u32x4 *)(es + (lane >> 2) * ES_B + (lane & 3) * 16);
+                const size_t prow = ((size_t)n * Hp + (oy0 >> 1) + rp) * Wp + (ox0 >> 1) + (lane >> 2);
+                if (lane < 32 && cbase < a.Cout) *(u32x4 *)&yh[prow * a.ldy + cbase] = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;            // GEMM row = 4 * window + corner
+                    *(_Float16 *)(es + rr * ES_B + li * 2) = (_Float16)epilogue_fast(acc[r], alpha, beta, ACT_);
+                }
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const int rr = (lane >> 2) + 16 * p2;
+                    const u32x4 v = *(const u32x4 *)(es + rr * ES_B + (lane & 3) * 16);
+                    const int oy = oy0 + 2 * rp + ((rr >> 1) & 1), ox = ox0 + 2 * (rr >> 2) + (rr & 1);
+                    if (cbase < a.Cout) *(u32x4 *)&yh[(((size_t)n * a.H + oy) * a.W + ox) * a.ldy + cbase] = v;
+                }
+            }
+        }
+        if (next < ntiles) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+}
+
+static bool c64_ok(const y2h_conv *d)
+{
+    if (!d->x_f16 || !d->y_f16 || d->x_halo || getenv("Y2_NO_C64")) return false;
+    if (d->size != 3 || d->stride != 1 || d->pad != 1 || d->c != 64 || d->n > 128 || d->n <= 64) return false;
+    if (d->out_h != d->h || d->out_w != d->w || (d->h & 15) || (d->w & 15) || d->ldx % 8 != 0) return false;
+    if (d->ldy % 8 != 0 || d->n % 8 != 0 || ((uintptr_t)d->y % 16) != 0) return false;            // 16-byte output stores only
+    if (((uintptr_t)d->x | (uintptr_t)d->w_packed) % 16 != 0) return false;
+    {
+        long min_tiles = 512;                                  // a plan for big batches: one workgroup per CU, >= 2 tiles each
+        if (const char *m = getenv("Y2_C64_MIN_TILES")) min_tiles = atol(m);
+        if ((long)d->batch * (d->h >> 4) * (d->w >> 4) < min_tiles) return false;
+    }
+    const double xbytes = (double)d->batch * d->h * d->w * d->ldx * 2.0;
+    return xbytes < 2147483000.0 && d->w_packed != nullptr;
+}
+
+static int c64_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
+{
+    if (!d->alpha || !d->beta) return Y2H_EINVAL;
+    a.w = d->w_packed;
+    a.alpha = d->alpha; a.beta = d->beta;
+    a.npix = d->batch * d->h * d->w;
+    a.xbytes = (unsigned)((size_t)d->batch * d->h * d->w * d->ldx * 2);
+    a.wbytes = (unsigned)((size_t)d->n * 576 * 2);
+    const bool lk = d->activation == Y2H_ACT_LEAKY;
+    void (*fn)(ConvK) = a.pool ? (lk ? conv_c64_f16_kernel<true, true> : conv_c64_f16_kernel<true, false>)
+                               : (lk ? conv_c64_f16_kernel<false, true> : conv_c64_f16_kernel<false, false>);
+    const size_t lds = (size_t)2 * 18 * 2688 + 8 * 32 * 80;
+    a.vec_store = 1;
+    {
+        static bool attr_set[16][4] = {{false}};
+        const int which = (a.pool ? 2 : 0) + (lk ? 1 : 0);
+        int dev = 0;
+        Y2H_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16 || !attr_set[dev][which]) {
+            Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 16) attr_set[dev][which] = true;
+        }
+    }
+    long tiles = (long)d->batch * (d->h >> 4) * (d->w >> 4);
+    long grid = tiles < 256 ? tiles : 256;               // one workgroup per CU, tiles are grid-strided
+    if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), lds, S(s), a);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
 bool y2_f16_conv_ok(const y2h_conv *d)
 {
     if (!d->x_f16) return false;
@@ -1310,6 +1495,7 @@ size_t y2_f16_conv_workspace_bytes(const y2h_conv *d);
 const char *y2_f16_conv_variant(const y2h_conv *d)
 {
     if (c32_ok(d)) return "conv_c32_f16_16x16";
+    if (c64_ok(d)) return "conv_c64_f16_16x16";
     VariantH *v = y2_f16_conv_ok(d) ? pick_h(d) : nullptr;
     return v ? v->name : nullptr;
 }
@@ -1317,6 +1503,7 @@ const char *y2_f16_conv_variant(const y2h_conv *d)
 int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
 {
     if (c32_ok(d)) return c32_launch(d, a, s);
+    if (c64_ok(d)) return c64_launch(d, a, s);
     VariantH *v = pick_h(d);
     if (!v || !d->alpha || !d->beta) return Y2H_EINVAL;
     a.w = d->w_packed;
@@ -1418,7 +1605,7 @@ int y2_f16_conv_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
 
 size_t y2_f16_conv_workspace_bytes(const y2h_conv *d)
 {
-    if (c32_ok(d) || !y2_f16_conv_ok(d)) return 0;
+    if (c32_ok(d) || c64_ok(d) || !y2_f16_conv_ok(d)) return 0;
     VariantH *v = pick_h(d);
     if (!v || !v->p8) return 0;
     const long npix = (long)d->batch * d->h * d->w;

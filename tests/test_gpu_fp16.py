@@ -178,3 +178,44 @@ def test_f16_avgpool_is_exact_on_integer_data(oracle, workdir, monkeypatch, filt
         out = net.network_predict(x)
         net.free()
         assert out.shape == ref.shape and np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("filters,size,batch", [(128, 48, 3), (96, 32, 5), (72, 64, 2)])
+def test_f16_c64_weights_stationary_kernel_is_exact(oracle, workdir, monkeypatch, filters, size, batch, pool):
+    """conv_c64_f16_kernel (3x3, 64 input channels, 65..128 filters, weights in registers, 18x18 input patch in LDS, 2x16
+    pixel strips in pool-major order): exact against the oracle on integer data with and without the fused 2x2 maxpool,
+    full and partial second filter half (96, 72), several tiles per workgroup (grid capped), image borders inside the
+    patch halo (convolutional_layer.c:435-474, maxpool_layer.c:79-114); with batch-norm + leaky the same bits as the
+    generic tile"""
+    monkeypatch.setenv("Y2_C64_MIN_TILES", "1")
+    monkeypatch.setenv("Y2_CONV_GRID", "4")
+    spec = [("conv", 64, 3, 0, "linear"), ("conv", filters, 3, 0, "linear")] + ([("max", 2, 2)] if pool else [])
+    cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 9950 + filters + size + pool)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    net.set_half(True)
+    out = net.network_predict(x)
+    assert net.layer_kernel(1) == "conv_c64_f16_16x16" + ("+maxpool2" if pool else ""), net.layer_kernel(1)
+    net.free()
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    assert np.abs(on.layer_output(0)).max() <= 2048 and np.abs(ref).max() < 60000
+    on.close()
+    assert np.array_equal(out, _as_half(ref))
+    # batch-norm + leaky (the compiled-in epilogue): equal to the generic kernel's result
+    spec = [("conv", 64, 3, 0, "linear"), ("conv", filters, 3, 1, "leaky")] + ([("max", 2, 2)] if pool else [])
+    cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 9980 + filters + size + pool, neg_scale=True)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("Y2_NO_C64", "1")
+        else:
+            monkeypatch.delenv("Y2_NO_C64", raising=False)
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        net.set_half(True)
+        outs.append(net.network_predict(x).copy())
+        assert net.layer_kernel(1).startswith("conv_c64") != off
+        net.free()
+    assert np.array_equal(outs[0], outs[1])
