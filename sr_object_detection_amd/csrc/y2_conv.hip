@@ -896,6 +896,195 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvK a)
 }
 
 // ---------------------------------------------------------------------------
+// 3x3 convolution with 32 input channels and <= 64 filters in fp32 (yolo.cfg layer 2: 304x304 32 -> 64 + pool at 608x608,
+// 0.91 ms of the 15.6 ms step at 0.76 of the matrix peak on the 64x64 tile, whose nine K-steps of 32 pay a barrier, a
+// staging round and a prologue / epilogue share each), weights stationary -- the plan of the fp16 conv_c32 / conv_c64
+// kernels carried over to v_mfma_f32_32x32x2_f32:
+//   * a wave owns ONE 32-filter tile: the lane's B operands W[filter li][tap][8 g + 4 h + s] (9 taps x 4 groups x 4 steps)
+//     are 144 VGPRs, loaded once per kernel; the eight waves of the one workgroup per CU are (filter tile fq, strip pair sg);
+//   * a workgroup walks 16x16-pixel output tiles; the 18x18-pixel input patch of the NEXT tile (128 B per pixel) is fetched
+//     into registers during the current tile's MFMAs and written to the other LDS buffer afterwards: one barrier per tile,
+//     none in the K loop; every input pixel reaches the CU once per tile (1.27x with the halo) instead of nine times;
+//   * an MFMA row tile is a 2 x 16 pixel strip in pool-major order; lane (pixel li, half h) takes channels 8 g + 4 h .. + 3 of
+//     a tap with ONE ds_read_b128, which feeds four MFMAs (the k pairing of conv_mfma_kernel).  Pixel pitch 144 B, row pitch
+//     2688 B: the 16-lane groups of a ds_read_b128 hit sixteen distinct 16-byte slots;
+//   * the epilogue is the reference's arithmetic (epilogue_f32 / pool_pick), outputs leave as 16-byte stores through a
+//     wave-private LDS transpose.
+// K order = (tap, channel): any order gives the same fp32 sum up to association; exact on integer data like every tile.
+// ---------------------------------------------------------------------------
+template <bool POOL, bool FAST>
+__global__ __launch_bounds__(512, 2) void conv_c32_f32_kernel(ConvK a)
+{
+    constexpr int PW = 18, PIX_B = 144, ROW_B = 2688, BUF_B = PW * ROW_B;
+    constexpr int NCH = PW * PW * 8;                 // 16-byte chunks of one patch
+    constexpr int NP = (NCH + 511) / 512;            // staging passes
+    constexpr int ES_B = 144;                        // scratch row: 32 filters x 4 B + 16 B
+    extern __shared__ __attribute__((aligned(16))) unsigned char c32_smem[];
+    const int t = threadIdx.x, lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fq = wv & 1, sg = wv >> 1;
+    const bool BN_ = FAST ? true : (bool)a.bn;
+    const int ACT_ = FAST ? (int)Y2H_ACT_LEAKY : a.act;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.ybytes, 0x00020000);
+
+    f32x4 bw[36];                                    // [tap * 4 + g]: W[co][tap][8 g + 4 lh .. + 3]
+    const int co = 32 * fq + li;
+    const bool cok = co < a.Cout;
+    float mean = 0.f, scale = 1.f, bias = 0.f;
+    double rinv = 1.0;
+    if (cok) {
+        bias = a.bias[co];
+        if (BN_) { mean = a.mean[co]; rinv = a.rinv[co]; scale = a.scale[co]; }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 36; ++kk) {
+        const unsigned off = cok ? (unsigned)((co * 288 + (kk >> 2) * 32 + (kk & 3) * 8 + 4 * lh) * 4) : a.wbytes;
+        bw[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+    }
+
+    const int ldxB = a.ldx * 4;
+    int s_lds[NP], s_rel[NP], s_yx[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int q = t + 512 * p;
+        const int pixel = q >> 3, part = q & 7;
+        const int py = pixel / PW, px = pixel - py * PW;
+        s_lds[p] = py * ROW_B + px * PIX_B + part * 16;
+        s_rel[p] = ((py - 1) * a.W + (px - 1)) * ldxB + part * 16;
+        s_yx[p] = q < NCH ? (py << 8) | px : -1;
+    }
+    const int tiles_x = a.W >> 4, tpi = (a.H >> 4) * tiles_x;
+    const int ntiles = a.batch * tpi;
+    u32x4 sreg[NP];
+    auto load_tile = [&](int tile) {
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int oy0 = (rem / tiles_x) << 4, ox0 = (rem - (rem / tiles_x) * tiles_x) << 4;
+        const int base = ((n * a.H + oy0) * a.W + ox0) * ldxB;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int iy = oy0 - 1 + (s_yx[p] >> 8), ix = ox0 - 1 + (s_yx[p] & 255);
+            const bool ok = s_yx[p] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            sreg[p] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)(base + s_rel[p]) : a.xbytes, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (s_yx[p] >= 0) *(u32x4 *)(c32_smem + buf * BUF_B + s_lds[p]) = sreg[p];
+    };
+
+    const int a_off = ((li >> 1) & 1) * ROW_B + (2 * (li >> 2) + (li & 1)) * PIX_B + lh * 16;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    float *es = (float *)(c32_smem + 2 * BUF_B + wv * 32 * ES_B);        // [32 rows][32 filters + pad], wave-private
+    const int cbase = 32 * fq + (lane & 7) * 4;                          // first of the 4 filters this lane stores
+    const bool fok = cbase < a.Cout;
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile < ntiles) { load_tile(tile); store_tile(0); }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next);
+        const int n = tile / tpi, rem = tile - n * tpi;
+        const int oy0 = (rem / tiles_x) << 4, ox0 = (rem - (rem / tiles_x) * tiles_x) << 4;
+#pragma unroll
+        for (int rpi = 0; rpi < 2; ++rpi) {
+            const int rp = 2 * sg + rpi;                       // strip = output rows oy0 + 2 rp, + 1
+            const unsigned char *ap = c32_smem + cur * BUF_B + 2 * rp * ROW_B + a_off;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 af = *(const f32x4 *)(ap + kh * ROW_B + kw * PIX_B + g * 32);
+                        const f32x4 bf = bw[(kh * 3 + kw) * 4 + g];
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s4], bf[s4], acc, 0, 0, 0);
+                    }
+            if (POOL) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    es[(2 * g + lh) * (ES_B / 4) + li] = epilogue_f32(pool_pick(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3],
+                                                                                !BN_ || scale >= 0.f), BN_, mean, rinv, scale, bias, ACT_);
+                const u32x4 v = *(const u32x4 *)&es[(lane >> 3) * (ES_B / 4) + (lane & 7) * 4];
+                const unsigned prow = (unsigned)((n * Hp + (oy0 >> 1) + rp) * Wp + (ox0 >> 1) + (lane >> 3));
+                const unsigned off = fok ? (prow * (unsigned)a.ldy + (unsigned)cbase) * 4u : 0xffffffffu;
+                __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;            // GEMM row = 4 * window + corner
+                    es[rr * (ES_B / 4) + li] = epilogue_f32(acc[r], BN_, mean, rinv, scale, bias, ACT_);
+                }
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int rr = (lane >> 3) + 8 * p4;
+                    const u32x4 v = *(const u32x4 *)&es[rr * (ES_B / 4) + (lane & 7) * 4];
+                    const int oy = oy0 + 2 * rp + ((rr >> 1) & 1), ox = ox0 + 2 * (rr >> 2) + (rr & 1);
+                    const unsigned off = fok ? ((unsigned)((n * a.H + oy) * a.W + ox) * (unsigned)a.ldy + (unsigned)cbase) * 4u : 0xffffffffu;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, yr, off, 0, 0);
+                }
+            }
+        }
+        if (next < ntiles) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+}
+
+static bool c32_f32_ok(const y2h_conv *d)
+{
+    if (d->x_f16 || d->y_f16 || d->x_halo || d->x_nchw || getenv("Y2_NO_C32F")) return false;
+    if (d->size != 3 || d->stride != 1 || d->pad != 1 || d->c != 32 || d->n > 64 || d->n % 4 != 0) return false;
+    if (d->out_h != d->h || d->out_w != d->w || (d->h & 15) || (d->w & 15) || d->ldx % 4 != 0 || d->ldy % 4 != 0) return false;
+    if (((uintptr_t)d->x | (uintptr_t)d->w_packed | (uintptr_t)d->y) % 16 != 0) return false;
+    if (d->tile_bm || d->ksplit > 1) return false;                         // a measured / forced tile choice wins
+    if (getenv("Y2_CONV_TILE")) return false;
+    {
+        long min_tiles = 512;                                              // a plan for big batches: one workgroup per CU, >= 2 tiles each
+        if (const char *m = getenv("Y2_C32F_MIN_TILES")) min_tiles = atol(m);
+        if ((long)d->batch * (d->h >> 4) * (d->w >> 4) < min_tiles) return false;
+    }
+    const double xbytes = (double)d->batch * d->h * d->w * d->ldx * 4.0;
+    const double ybytes = (double)d->batch * d->h * d->w * (d->fuse_maxpool2 ? 0.25 : 1.0) * d->ldy * 4.0;
+    return xbytes < 4294967000.0 && ybytes < 4294967000.0 && d->w_packed != nullptr;
+}
+
+static int c32_f32_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
+{
+    a.w = d->w_packed;
+    a.npix = d->batch * d->h * d->w;
+    a.xbytes = (unsigned)((size_t)d->batch * d->h * d->w * d->ldx * 4);
+    a.wbytes = (unsigned)((size_t)d->n * 288 * 4);
+    a.ybytes = (unsigned)((size_t)(d->fuse_maxpool2 ? a.npix / 4 : a.npix) * d->ldy * 4);
+    const bool fast = d->batch_normalize && d->activation == Y2H_ACT_LEAKY;
+    void (*fn)(ConvK) = a.pool ? (fast ? conv_c32_f32_kernel<true, true> : conv_c32_f32_kernel<true, false>)
+                               : (fast ? conv_c32_f32_kernel<false, true> : conv_c32_f32_kernel<false, false>);
+    const size_t lds = (size_t)2 * 18 * 2688 + 8 * 32 * 144;
+    {
+        static bool attr_set[16][4] = {{false}};
+        const int which = (a.pool ? 2 : 0) + (fast ? 1 : 0);
+        int dev = 0;
+        Y2H_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16 || !attr_set[dev][which]) {
+            Y2H_CHECK(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 16) attr_set[dev][which] = true;
+        }
+    }
+    long tiles = (long)d->batch * (d->h >> 4) * (d->w >> 4);
+    long grid = tiles < 256 ? tiles : 256;
+    if (const char *g = getenv("Y2_CONV_GRID")) { if (atol(g) > 0 && atol(g) < grid) grid = atol(g); }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), lds, S(s), a);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
 // direct kernel (reference accumulation order; bit-identical to the CPU path)
 // weights in the reference's [n][c][kh][kw] layout
 // ---------------------------------------------------------------------------
@@ -1114,6 +1303,7 @@ extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)
 {
     int ksplit = 1;
     if (d->x_f16 && !d->x_halo) return y2_f16_conv_workspace_bytes(d);      // stream-K piece slots of the fp16 256x256 kernel
+    if (c32_f32_ok(d)) return 0;
     if (d->x_halo || d->x_f16 || !mfma_ok(d) || !pick_variant(d, &ksplit) || ksplit <= 1) return 0;
     return (size_t)ksplit * d->batch * d->out_h * d->out_w * d->n * sizeof(float);
 }
@@ -1209,6 +1399,7 @@ extern "C" const char *y2h_conv_variant(const y2h_conv *d, int strict)
         const char *nm = strict ? nullptr : y2_f16_conv_variant(d);
         return nm ? nm : "conv_direct_f16";
     }
+    if (!strict && c32_f32_ok(d)) return "conv_c32_f32_16x16";
     if (!strict && d->x_halo == 0 && mfma_ok(d)) {
         Variant *v = pick_variant(d);
         if (v) return v->name;
@@ -1274,6 +1465,7 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         return Y2H_OK;
     }
     if (!strict && y2_f16_conv_ok(d)) return y2_f16_conv_launch(d, a, s);
+    if (!strict && c32_f32_ok(d)) return c32_f32_launch(d, a, s);
     int ksplit = 1;
     Variant *v = (!strict && d->x_halo == 0 && mfma_ok(d)) ? pick_variant(d, &ksplit) : nullptr;
     if (!v && !strict && stem_ok(d)) {

@@ -353,6 +353,47 @@ def test_f16_first_layer_reads_the_nchw_input(oracle, workdir, monkeypatch, filt
             assert np.abs(outs[0] - ref).max() <= np.abs(ref).max() * 2.0 ** -10
 
 
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("filters,size,batch", [(64, 48, 3), (48, 32, 5), (20, 64, 2)])
+def test_f32_c32_weights_stationary_kernel_is_exact(oracle, workdir, monkeypatch, filters, size, batch, pool):
+    """conv_c32_f32_kernel (3x3, 32 input channels, <= 64 filters in fp32: weights in registers, 18x18 input patch in LDS,
+    2x16 pixel strips in pool-major order, v_mfma_f32_32x32x2_f32 with the k pairing of the generic kernel): exact against the
+    oracle on integer data with and without the fused 2x2 maxpool, full / partial / single filter tile, several tiles per
+    workgroup, image borders inside the patch halo (convolutional_layer.c:435-474, maxpool_layer.c:79-114).  With batch-norm
+    + leaky and negative scales: the same bits as the generic tile kernel (same accumulator on integer data, same
+    epilogue_f32 / pool_pick arithmetic)"""
+    monkeypatch.setenv("Y2_C32F_MIN_TILES", "1")
+    monkeypatch.setenv("Y2_CONV_GRID", "4")
+    monkeypatch.delenv("Y2_CONV_TILE", raising=False)
+    spec = [("conv", 32, 3, 0, "linear"), ("conv", filters, 3, 0, "linear")] + ([("max", 2, 2)] if pool else [])
+    cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 85000 + filters + size + pool)
+    net = darknet.Network.parse_network_cfg(cfg)
+    net.load_weights(wts)
+    out = net.network_predict(x)
+    assert net.layer_kernel(1) == "conv_c32_f32_16x16" + ("+maxpool2" if pool else ""), net.layer_kernel(1)
+    net.free()
+    on = oracle.OracleNet(cfg, wts)
+    ref = on.predict(x)
+    on.close()
+    assert np.abs(ref).max() < 2 ** 22
+    assert np.array_equal(out, ref)
+    spec = [("conv", 32, 3, 0, "linear"), ("conv", filters, 3, 1, "leaky")] + ([("max", 2, 2)] if pool else [])
+    cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 85500 + filters + size + pool, neg_scale=True)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("Y2_NO_C32F", "1")
+        else:
+            monkeypatch.delenv("Y2_NO_C32F", raising=False)
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        outs.append(net.network_predict(x).copy())
+        assert net.layer_kernel(1).startswith("conv_c32_f32") != off, net.layer_kernel(1)
+        net.free()
+    assert np.array_equal(outs[0], outs[1])
+    assert (outs[0] < 0).any() and (outs[0] > 0).any()
+
+
 def test_kernel_name_pattern():
     for n in sorted(TESTED_F32 | TESTED_F16):
         assert re.fullmatch(r"conv_mfma_f(32|16)_\d+x\d+x\d+_k[13]", n)
