@@ -691,12 +691,22 @@ __global__ __launch_bounds__(512, 1) void conv_p8_f16_kernel(ConvK a)
                 delta = ((kh - 1) * a.W + (kw - 1)) * a.ldx;
             }
             const unsigned add = (unsigned)((delta + s_c0) * 2);
-            const bool ok = (a_msk[Q] >> s_tap) & 1u;
+            bool ok = (a_msk[Q] >> s_tap) & 1u;
+#ifdef P8_ABLATE
+            // timing ablation (wrong results; tools/build_variant.sh ablate -DP8_ABLATE, Y2_DBG bits): 128 = the A half-tiles of every
+            // tap but the centre one are fetched out of range (zeros, no memory traffic; same instruction count and waits):
+            // what re-using ONE staged input patch for the nine taps would save on the L2 -> LDS path; 256 = the same for B
+            if ((a.dbg & 128) && KS == 3 && s_tap != 4) ok = false;
+            if ((a.dbg & 512) && KS == 3 && s_tap != 4) return;      // 512 = those DMA instructions are not issued at all (the counted waits then pass early)
+#endif
             const unsigned off = ok ? a_off[Q] + add : a.xbytes;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void *)dst, 16, off, 0, 0, 0);
         } else {
             const unsigned kadd = (unsigned)((s_tap * a.Cin + s_c0) * 2);
-            const unsigned off = (b_off[Q] == a.wbytes) ? a.wbytes : b_off[Q] + kadd;
+            unsigned off = (b_off[Q] == a.wbytes) ? a.wbytes : b_off[Q] + kadd;
+#ifdef P8_ABLATE
+            if (a.dbg & 256) off = a.wbytes;
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void *)dst, 16, off, 0, 0, 0);
         }
     };
