@@ -85,36 +85,21 @@ Detector::~Detector()
 int Detector::get_net_width() const { return state_of(detector_gpu_ptr).net.w; }
 int Detector::get_net_height() const { return state_of(detector_gpu_ptr).net.h; }
 
-// Binary PPM (P6, maxval 255) reader.  The reference decodes JPEG/PNG through the vendored
-// stb_image (cpp:127-149); file decoding is outside the engine, so only the dependency-free
-// format is read here -- callers with other formats fill image_t themselves (or use OpenCV).
+// Image file -> planar RGB floats in [0,1], three channels whatever the file holds (the reference calls
+// stbi_load(..., 3) and divides by 255., cpp:127-149).  PNG, baseline JPEG and binary PNM are decoded by
+// y2_imgfile.cpp (dependency-free; progressive JPEG is refused with a message); a missing file throws
+// "file not found" as the reference does.
+void y2_decode_image_file(const std::string &path, int &w, int &h, std::vector<unsigned char> &rgb);
+
 image_t Detector::load_image(std::string image_filename)
 {
-    FILE *f = std::fopen(image_filename.c_str(), "rb");
-    if (!f) throw std::runtime_error("file not found");
-    int w = 0, h = 0, maxv = 0;
-    char magic[3] = {0, 0, 0};
-    if (std::fscanf(f, "%2s", magic) != 1 || std::strcmp(magic, "P6") != 0) { std::fclose(f); throw std::runtime_error("load_image: only binary PPM (P6) is supported"); }
-    int got = 0, vals[3];
-    while (got < 3) {
-        int ch = std::fgetc(f);
-        if (ch == '#') { while (ch != '\n' && ch != EOF) ch = std::fgetc(f); continue; }
-        if (ch == EOF) break;
-        if (std::isspace(ch)) continue;
-        std::ungetc(ch, f);
-        if (std::fscanf(f, "%d", &vals[got]) != 1) break;
-        ++got;
-    }
-    if (got != 3) { std::fclose(f); throw std::runtime_error("load_image: bad PPM header"); }
-    w = vals[0]; h = vals[1]; maxv = vals[2];
-    std::fgetc(f);
-    if (w <= 0 || h <= 0 || maxv != 255) { std::fclose(f); throw std::runtime_error("load_image: unsupported PPM"); }
-    std::vector<unsigned char> raw((size_t)w * h * 3);
-    if (std::fread(raw.data(), 1, raw.size(), f) != raw.size()) { std::fclose(f); throw std::runtime_error("load_image: short PPM"); }
-    std::fclose(f);
+    int w = 0, h = 0;
+    std::vector<unsigned char> raw;
+    y2_decode_image_file(image_filename, w, h, raw);
     image_t im;
     im.w = w; im.h = h; im.c = 3;
     im.data = (float *)std::calloc((size_t)w * h * 3, sizeof(float));
+    if (!im.data) throw std::runtime_error("load_image: out of memory");
     for (int k = 0; k < 3; ++k)
         for (int j = 0; j < h; ++j)
             for (int i = 0; i < w; ++i)

@@ -8,6 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$(mktemp -d)
 C=$ROOT/sr_object_detection_amd/csrc
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g -fPIC"
+g++ $SAN -std=c++17 -c $C/y2_imgfile.cpp -o $OUT/y2_imgfile.o
 for f in y2_cfg y2_weights y2_engine y2_detect y2_eval y2_comm y2_feed; do
     gcc $SAN -ffp-contract=off -std=gnu11 -I$ROOT/include -I$C/host -c $C/host/$f.c -o $OUT/$f.o
 done
