@@ -504,7 +504,43 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             }
         }
     };
-    if (VST && a.vec_store && a.bn && a.act == Y2H_ACT_LEAKY) {        // (every conv of the target cfgs but the last)
+    // split-K: the raw partial sums of this K range go to their workspace slab [pixel][filter] as 16-byte stores through the
+    // same wave-private LDS transpose (the scalar form below -- one 4-byte store with a 64-bit address per value, 96 per lane
+    // of a 192x256 tile -- cost a batch-1 work item of 8-14 K-steps 6-12 k cycles: profiles/r02_notes.md)
+    auto partial_pass = [&]() {
+        const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ws + (size_t)ks * a.npix * a.Cout), 0,
+                                                                             (unsigned)((size_t)a.npix * a.Cout * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float *es = (ES_OWN ? smem + 2 * BUF : smem + (cur ^ 1) * BUF) + wv * (16 * ES);
+                const int cb = n0 + wn * (BN / WN) + j * 32, pb = p0 + wm * (BM / WM) + i * 32;
+                const int rrow = lane >> 3, rch = (lane & 7) * 4;
+                const bool fok = cb + rch < a.Cout;
+                const unsigned base = ((unsigned)(pb + rrow) * (unsigned)a.Cout + (unsigned)(cb + rch)) * 4u;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) es[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + li] = acc[i][j][8 * h2 + r];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const u32x4 v = *(const u32x4 *)&es[(rrow + 8 * u) * ES + rch];
+                        const int p = pb + 16 * h2 + rrow + 8 * u;
+                        const unsigned off = (fok && p < a.npix) ? base + (unsigned)(16 * h2 + 8 * u) * (unsigned)a.Cout * 4u : 0xffffffffu;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, wsr, off, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    if (a.ksplit > 1 && (a.Cout & 3) == 0) {
+        partial_pass();
+        if (!ES_OWN) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else if (VST && a.vec_store && a.bn && a.act == Y2H_ACT_LEAKY) {        // (every conv of the target cfgs but the last)
         epilogue_pass(std::integral_constant<int, 1>{}, std::true_type{});
         if (!ES_OWN) {            // the scratch lies in the buffer the next K-step stores its slice into
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -101,6 +101,16 @@ def test_f32_tile_split_k_is_exact(oracle, workdir, monkeypatch, tile, pool):
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("tile", [(192, 256), (128, 128), (64, 64)], ids=lambda t: "%dx%d" % t)
+def test_f32_split_k_scalar_store_fallback_is_exact(oracle, workdir, monkeypatch, tile):
+    """a filter count that is no multiple of 4: the partial sums take the scalar store path instead of the 16-byte one"""
+    bm, bn = tile
+    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=96, filters=bn + 37, ksize=3, size=19, batch=3,
+                             tile=tile, pool=False, ksplit=3, seed=5500 + bm + bn)
+    assert name == "conv_mfma_f32_%dx%dx32_k3" % (bm, bn), name
+    assert np.array_equal(out, ref)
+
+
 @pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
 @pytest.mark.parametrize("tile", F32_TILES_BK32, ids=lambda t: "%dx%d" % t)
 def test_f32_tile_with_batchnorm_leaky_epilogue(oracle, workdir, monkeypatch, tile, pool):
