@@ -173,6 +173,8 @@ unsigned long y2h_stream_k_launches(void);
 unsigned long y2h_tail_launches(void);
 /* number of fp32 matrix-core launches that used the XCD-grouped tile order (wide heads: yolo9000's final 1x1) */
 unsigned long y2h_xcd_order_launches(void);
+/* number of fp32 matrix-core launches that used stream-K work items (grids smaller than the machine) */
+unsigned long y2h_f32_stream_k_launches(void);
 /* 1 when the shape fits the dedicated first-layer kernel (3 channels, 3x3/1 pad 1, <= 64
  * filters) provided the input is supplied with a halo (x_halo = 1) */
 int y2h_conv_first_layer_ok(const y2h_conv *d);

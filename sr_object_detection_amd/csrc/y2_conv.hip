@@ -56,7 +56,7 @@
 // ---------------------------------------------------------------------------
 // MFMA implicit GEMM
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int BK, int KS, int WM, int WN, bool PIPE, bool XO = false>
+template <int BM, int BN, int BK, int KS, int WM, int WN, bool PIPE, bool XO = false, bool SKM = false>
 __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 {
     constexpr int NT = WM * WN * 64;
@@ -103,11 +103,29 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     const int nk = KS * KS * (a.Cin / BK);
     int tap = 0, c0 = 0;      // position of the NEXT slice to load
     int s_k = 0, s_n = 0;     // staging cursor: slices of its work item already fetched / slices that item has
+    // SKM (stream-K, grids smaller than the machine: batch 1 .. 8): the ntiles * nk K-steps of ALL output tiles are dealt in
+    // equal contiguous shares to the sk_wgs workgroups (a share never exceeds one tile: ntiles <= sk_wgs), so a workgroup has
+    // at most two work items = pieces (tile, K range); work item v in {0, 1} is piece v, its raw sums go to workspace slot
+    // 2 * wg + v in tile-local layout [BM][BN], and sk_reduce_kernel adds a tile's pieces in ascending K order.  Against
+    // the integer split-K above every workgroup gets the same number of K-steps whatever the tile count.
+    int n_sk = 0, sk_t0 = 0, sk_kb0 = 0, sk_ke0 = 0, sk_ke1 = 0;
+    if constexpr (SKM) {
+        const long I = (long)a.sk_tiles * nk;
+        const long lo = (long)blockIdx.x * I / a.sk_wgs, hi = (long)(blockIdx.x + 1) * I / a.sk_wgs;
+        if (hi > lo) {
+            const int t0 = (int)(lo / nk), k0 = (int)(lo - (long)t0 * nk), len = (int)(hi - lo);
+            sk_t0 = t0; sk_kb0 = k0; sk_ke0 = k0 + len < nk ? k0 + len : nk; n_sk = 1;
+            if (k0 + len > nk) { sk_ke1 = k0 + len - nk; n_sk = 2; }
+        }
+    }
+    const int END = SKM ? 2 : a.ntiles;       // work-item number that means "past the end"
     auto setup_tile = [&](int vtile) {
-    const bool live = vtile < a.ntiles;
-    const int tile = vtile / a.ksplit;
-    const int kb = ((vtile - tile * a.ksplit) * nk) / a.ksplit;     // first slice of this work item
-    s_n = live ? (((vtile - tile * a.ksplit) + 1) * nk) / a.ksplit - kb : 0x40000000;    // past the end: never hop again
+    const bool live = vtile < END;
+    const int tile = SKM ? sk_t0 + (vtile & 1) : vtile / a.ksplit;
+    const int kb = SKM ? (vtile == 0 ? sk_kb0 : 0) : ((vtile - tile * a.ksplit) * nk) / a.ksplit;     // first slice of this work item
+    s_n = !live ? 0x40000000                                                                       // past the end: never hop again
+          : SKM ? (vtile == 0 ? sk_ke0 - sk_kb0 : sk_ke1)
+                : (((vtile - tile * a.ksplit) + 1) * nk) / a.ksplit - kb;
     c0 = (kb / (KS * KS)) * BK;
     tap = kb % (KS * KS);
     const int p0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
@@ -190,6 +208,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             }
             return (pb * a.pblk + pi) * a.tiles_n + xcd + 8 * fi;
         }
+        if constexpr (SKM) return i < n_sk ? i : END;
         const long tl = (long)wgid + (long)i * gridDim.x;
         return tl < a.ntiles ? (int)tl : a.ntiles;
     };
@@ -291,9 +310,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 #endif
     for (int cti = 0;; ++cti) {
     const int vt = tile_at(cti);
-    if (vt >= a.ntiles) break;
-    const int ct = vt / a.ksplit, ks = vt - ct * a.ksplit;
-    const int kb = (ks * nk) / a.ksplit, ke = ((ks + 1) * nk) / a.ksplit;
+    if (vt >= END) break;
+    const int ct = SKM ? sk_t0 + vt : vt / a.ksplit, ks = SKM ? 2 * (int)blockIdx.x + vt : vt - ct * a.ksplit;       // SKM: ks = piece slot
+    const int kb = SKM ? (vt == 0 ? sk_kb0 : 0) : (ks * nk) / a.ksplit, ke = SKM ? (vt == 0 ? sk_ke0 : sk_ke1) : ((ks + 1) * nk) / a.ksplit;
     const int p0 = (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -508,17 +527,20 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     // same wave-private LDS transpose (the scalar form below -- one 4-byte store with a 64-bit address per value, 96 per lane
     // of a 192x256 tile -- cost a batch-1 work item of 8-14 K-steps 6-12 k cycles: profiles/r02_notes.md)
     auto partial_pass = [&]() {
-        const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ws + (size_t)ks * a.npix * a.Cout), 0,
-                                                                             (unsigned)((size_t)a.npix * a.Cout * 4), 0x00020000);
+        // slab of this work item: split-K [pixel][filter] of K range ks; stream-K: slot ks, tile-local [BM][BN]
+        const __amdgpu_buffer_rsrc_t wsr = SKM
+            ? __builtin_amdgcn_make_buffer_rsrc((void *)(a.ws + (size_t)ks * (BM * BN)), 0, (unsigned)(BM * BN * 4), 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc((void *)(a.ws + (size_t)ks * a.npix * a.Cout), 0, (unsigned)((size_t)a.npix * a.Cout * 4), 0x00020000);
+        const unsigned ldw = SKM ? (unsigned)BN : (unsigned)a.Cout;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float *es = (ES_OWN ? smem + 2 * BUF : smem + (cur ^ 1) * BUF) + wv * (16 * ES);
-                const int cb = n0 + wn * (BN / WN) + j * 32, pb = p0 + wm * (BM / WM) + i * 32;
+                const int cb = (SKM ? 0 : n0) + wn * (BN / WN) + j * 32, pb = (SKM ? 0 : p0) + wm * (BM / WM) + i * 32;
                 const int rrow = lane >> 3, rch = (lane & 7) * 4;
-                const bool fok = cb + rch < a.Cout;
-                const unsigned base = ((unsigned)(pb + rrow) * (unsigned)a.Cout + (unsigned)(cb + rch)) * 4u;
+                const bool fok = SKM || cb + rch < a.Cout;
+                const unsigned base = ((unsigned)(pb + rrow) * ldw + (unsigned)(cb + rch)) * 4u;
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
@@ -527,14 +549,14 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                     for (int u = 0; u < 2; ++u) {
                         const u32x4 v = *(const u32x4 *)&es[(rrow + 8 * u) * ES + rch];
                         const int p = pb + 16 * h2 + rrow + 8 * u;
-                        const unsigned off = (fok && p < a.npix) ? base + (unsigned)(16 * h2 + 8 * u) * (unsigned)a.Cout * 4u : 0xffffffffu;
+                        const unsigned off = (fok && (SKM || p < a.npix)) ? base + (unsigned)(16 * h2 + 8 * u) * ldw * 4u : 0xffffffffu;
                         __builtin_amdgcn_raw_buffer_store_b128(v, wsr, off, 0, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
-    if (a.ksplit > 1 && (a.Cout & 3) == 0) {
+    if (SKM || (a.ksplit > 1 && (a.Cout & 3) == 0)) {
         partial_pass();
         if (!ES_OWN) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -588,6 +610,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK a)
         float sum = a.ws[idx];
         for (int s = 1; s < a.ksplit; ++s) sum += a.ws[(size_t)s * slab + idx];
         a.y[(size_t)p * a.ldy + co] = epilogue_f32(sum, a.bn, mean, rinv, scale, bias, a.act);
+    }
+}
+
+// second pass of a stream-K convolution (conv_mfma_kernel<..., SKM>): y[p][co .. co+3] = epilogue(sum of the pieces of the
+// output's tile, ascending K = ascending workgroup).  A piece slot holds a whole tile in tile-local layout [bm][bn]; the
+// pieces of tile t are those of the workgroups whose share [w * I / G, (w + 1) * I / G) reaches into [t * nk, (t + 1) * nk):
+// slot 2 w + (1 if the share began in the previous tile).  Cout and ldy multiples of 4 (the host checks).
+__global__ __launch_bounds__(256) void sk_reduce_kernel(ConvK a, int bm, int bn, int nk)
+{
+    const int c4 = a.Cout >> 2;
+    const long rows = a.pool ? (long)a.npix >> 2 : (long)a.npix;
+    const long total = rows * c4, I = (long)a.sk_tiles * nk, G = a.sk_wgs;
+    const int nt = a.pool ? 4 : 1;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int q = (int)(idx % c4), co = q * 4;
+        const long p = idx / c4;
+        const long g0 = a.pool ? 4 * p : p;                     // first GEMM row of this output (a pooling window's four rows share a tile: bm % 4 == 0)
+        const int tile = (int)(g0 / bm) * a.tiles_n + co / bn;
+        const int r0 = (int)(g0 % bm), c = co % bn;
+        const long tb = (long)tile * nk, te = tb + nk;
+        long w = tb * G / I;
+        while (w > 0 && w * I / G > tb) --w;
+        while (w + 1 < G && (w + 1) * I / G <= tb) ++w;
+        f32x4 sums[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sums[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (; w < G; ++w) {
+            const long lo = w * I / G, hi = (w + 1) * I / G;
+            if (lo >= te) break;
+            if (hi <= lo) continue;
+            const float *slot = a.ws + (size_t)(2 * w + (lo < tb ? 1 : 0)) * ((size_t)bm * bn);
+            for (int t = 0; t < nt; ++t) sums[t] = sums[t] + *(const f32x4 *)&slot[(size_t)(r0 + t) * bn + c];
+        }
+        f32x4 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float mean = 0.f, scale = 1.f;
+            double rinv = 1.0;
+            if (a.bn) { mean = a.mean[co + k]; rinv = a.rinv[co + k]; scale = a.scale[co + k]; }
+            const float v = a.pool ? pool_pick(sums[0][k], sums[1][k], sums[2][k], sums[3][k], !a.bn || scale >= 0.f) : sums[0][k];
+            out[k] = epilogue_f32(v, a.bn, mean, rinv, scale, a.bias[co + k], a.act);
+        }
+        *(f32x4 *)&a.y[(size_t)p * a.ldy + co] = out;
     }
 }
 
@@ -1171,15 +1236,21 @@ struct Variant {
     bool attr_set[16];     // per device
     void (*fn_xo)(ConvK);  // the same tile with the XCD-grouped tile order (ConvK.xcd_order), where instantiated
     bool attr_set_xo[16];
+    void (*fn_sk)(ConvK);  // the same tile with stream-K work items (ConvK.sk_tiles / sk_wgs), where instantiated
+    bool attr_set_sk[16];
 };
 
 #define VAR(BM, BN, BK, KS, WM, WN)                                                             \
     { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
-      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, nullptr, {false} }
+      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, nullptr, {false}, nullptr, {false} }
+#define VARSK(BM, BN, BK, KS, WM, WN)                                                           \
+    { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
+      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, \
+      nullptr, {false}, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, false, true>, {false} }
 #define VARXO(BM, BN, BK, KS, WM, WN)                                                           \
     { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
       (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, \
-      conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, true>, {false} }
+      conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, true>, {false}, nullptr, {false} }
 
 #ifndef Y2_PIPE
 #define Y2_PIPE true
@@ -1187,11 +1258,11 @@ struct Variant {
 static Variant g_variants[] = {
     // 8 waves (2 per SIMD), ONE workgroup per CU: the co-resident partner wave that hides LDS/barrier
     // stalls comes from the same workgroup, so a CU never ends up with a lone half-speed pair in the tail
-    VAR(192, 256, 32, 3, 2, 4), VARXO(192, 256, 32, 1, 2, 4),
+    VARSK(192, 256, 32, 3, 2, 4), VARXO(192, 256, 32, 1, 2, 4),
     VAR(256, 128, 32, 3, 4, 2), VAR(256, 128, 32, 1, 4, 2),
     VAR(256, 64, 32, 3, 8, 1),  VAR(256, 64, 32, 1, 8, 1),
     // 4 waves, two workgroups per CU
-    VAR(128, 128, 32, 3, 2, 2), VARXO(128, 128, 32, 1, 2, 2),
+    VARSK(128, 128, 32, 3, 2, 2), VARXO(128, 128, 32, 1, 2, 2),
     VAR(128, 64, 32, 3, 2, 2),  VAR(128, 64, 32, 1, 2, 2),
     VAR(64, 64, 32, 3, 2, 2),   VARXO(64, 64, 32, 1, 2, 2),
     VAR(128, 32, 32, 3, 4, 1),  VAR(128, 32, 32, 1, 4, 1),
@@ -1242,7 +1313,12 @@ static int variant_bpc(const Variant &v)               // workgroups co-resident
 // Split-K: when even the best tile shape leaves most CUs idle (13x13 grids at small batch, batch-1
 // inference), each output tile is cut into `ksplit` K ranges computed by different workgroups; the
 // partial sums go through an fp32 workspace and splitk_reduce_kernel.  Chosen together with the tile.
-static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
+static unsigned long g_skf_launches = 0;
+extern "C" unsigned long y2h_f32_stream_k_launches(void) { return g_skf_launches; }
+
+// sk_wgs_out (optional): > 0 when the choice is the stream-K form of the tile (conv_mfma_kernel<..., SKM>) on that many
+// workgroups -- then *ksplit_out is 1.  Env: Y2_SKF=0 off; Y2_SKF_WGS=n forces stream-K on n workgroups for the (forced) tile.
+static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr, int *sk_wgs_out = nullptr)
 {
     const int bk = (d->c % 32 == 0) ? 32 : 16;
     const long npix = (long)d->batch * d->out_h * d->out_w;
@@ -1253,7 +1329,11 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
     if (const char *f = getenv("Y2_CONV_KSPLIT")) force_split = atoi(f);
     Variant *best = nullptr;
     double best_cost = 0;
-    int best_split = 1;
+    int best_split = 1, best_sk = 0;
+    bool sk_on = true;
+    long sk_force = 0;
+    if (const char *f = getenv("Y2_SKF")) sk_on = atoi(f) != 0;
+    if (const char *f = getenv("Y2_SKF_WGS")) sk_force = atol(f);
     for (Variant &v : g_variants) {
         if (v.bk != bk || v.ks != d->size) continue;
         if (force_bm && (v.bm != force_bm || v.bn != force_bn)) continue;
@@ -1292,9 +1372,32 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr)
             best = &v;
             best_cost = cost;
             best_split = ksplit;
+            best_sk = 0;
+        }
+        // Stream-K candidate of the same tile (grids smaller than the machine): every workgroup gets tiles * nk / wgs K-steps,
+        // whatever the tile count -- the integer split above leaves CUs idle whenever tiles * ksplit is not a multiple of the
+        // slots (113 tiles x 2 = 226 of 256) and cannot cut a tile into 2.5.  Costs: up to two work items per workgroup (their
+        // fixed cost once and a half), pieces = wgs + tiles slots of bm x bn floats written and read once, one more launch.
+        if (sk_wgs_out && v.fn_sk && d->n % 4 == 0 && d->ldy % 4 == 0 && force_split <= 0 && d->tile_bm == 0 && nk >= 16 && sk_on) {
+            long wgs = (long)CUS * bpc;
+            if (wgs > tiles * nk / 8) wgs = tiles * nk / 8;             // shares of >= 8 K-steps
+            if (sk_force > 0) wgs = sk_force;
+            if (tiles <= wgs && wgs >= 2 && (sk_force > 0 || tiles * 2 < (long)CUS * bpc * 2)) {
+                const double share = (double)tiles * nk / wgs;
+                const long cu_load = (wgs + CUS - 1) / CUS;                // workgroups a CU hosts
+                double c_sk = (double)cu_load * v.bm * v.bn * v.bk / 128.0 * (share + 7.5) / eff;
+                c_sk += (double)(wgs + tiles) * v.bm * v.bn * 4.0 * 2.0 * 5.75e-4 + 5000.0;
+                if (sk_force > 0 || c_sk < best_cost * 0.97) {
+                    best = &v;
+                    best_cost = sk_force > 0 ? 0.0 : c_sk;
+                    best_split = 1;
+                    best_sk = (int)wgs;
+                }
+            }
         }
     }
     if (ksplit_out) *ksplit_out = best_split;
+    if (sk_wgs_out) *sk_wgs_out = best_sk;
     return best;
 }
 
@@ -1340,7 +1443,11 @@ extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)
     int ksplit = 1;
     if (d->x_f16 && !d->x_halo) return y2_f16_conv_workspace_bytes(d);      // stream-K piece slots of the fp16 256x256 kernel
     if (c32_f32_ok(d)) return 0;
-    if (d->x_halo || d->x_f16 || !mfma_ok(d) || !pick_variant(d, &ksplit) || ksplit <= 1) return 0;
+    int sk_wgs = 0;
+    Variant *v = (d->x_halo || d->x_f16 || !mfma_ok(d)) ? nullptr : pick_variant(d, &ksplit, &sk_wgs);
+    if (!v) return 0;
+    if (sk_wgs > 0) return (size_t)2 * sk_wgs * v->bm * v->bn * sizeof(float);          // stream-K piece slots
+    if (ksplit <= 1) return 0;
     return (size_t)ksplit * d->batch * d->out_h * d->out_w * d->n * sizeof(float);
 }
 
@@ -1502,8 +1609,13 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     }
     if (!strict && y2_f16_conv_ok(d)) return y2_f16_conv_launch(d, a, s);
     if (!strict && c32_f32_ok(d)) return c32_f32_launch(d, a, s);
-    int ksplit = 1;
-    Variant *v = (!strict && d->x_halo == 0 && mfma_ok(d)) ? pick_variant(d, &ksplit) : nullptr;
+    int ksplit = 1, sk_wgs = 0;
+    Variant *v = (!strict && d->x_halo == 0 && mfma_ok(d)) ? pick_variant(d, &ksplit, &sk_wgs) : nullptr;
+    if (v && sk_wgs > 0 && (!d->ws || d->ws_bytes < (size_t)2 * sk_wgs * v->bm * v->bn * sizeof(float) || ((uintptr_t)d->y % 16) != 0 ||
+                            ((uintptr_t)d->ws % 16) != 0)) {
+        sk_wgs = 0;                                       // no room for the piece slots: the integer split of the same descriptor
+        v = pick_variant(d, &ksplit);
+    }
     if (!v && !strict && stem_ok(d)) {
         a.w = d->w_packed;
         a.npix = d->batch * d->out_h * d->out_w;
@@ -1583,6 +1695,26 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         Y2H_CHECK(hipMemsetAsync(d_st, 0, 1024 * 8 * 5 * sizeof(unsigned long long), S(s)));
         a.stamps = d_st;
 #endif
+        if (sk_wgs > 0) {
+            // stream-K: all output tiles' K loops in equal shares over sk_wgs workgroups, then the piece reduction
+            a.sk_tiles = (int)(tiles_m * a.tiles_n);
+            a.sk_wgs = sk_wgs;
+            a.ws = d->ws;
+            a.ksplit = 1;
+            a.xcd_order = 0;
+            if (dev < 0 || dev >= 16 || !v->attr_set_sk[dev]) {
+                Y2H_CHECK(hipFuncSetAttribute((const void *)v->fn_sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
+                if (dev >= 0 && dev < 16) v->attr_set_sk[dev] = true;
+            }
+            hipLaunchKernelGGL(v->fn_sk, dim3((unsigned)sk_wgs), dim3(v->threads), v->lds, S(s), a);
+            Y2H_LAUNCH_CHECK();
+            const long outs4 = (long)(d->fuse_maxpool2 ? a.npix / 4 : a.npix) * (a.Cout / 4);
+            hipLaunchKernelGGL(sk_reduce_kernel, dim3(y2h_grid(outs4, 256)), dim3(256), 0, S(s), a, v->bm, v->bn,
+                               d->size * d->size * (d->c / v->bk));
+            Y2H_LAUNCH_CHECK();
+            ++g_skf_launches;
+            return Y2H_OK;
+        }
         if (a.xcd_order) {
             ++g_xcd_order_launches;
             if (dev < 0 || dev >= 16 || !v->attr_set_xo[dev]) {

@@ -238,6 +238,7 @@ def lib():
     L.y2h_stream_k_launches.restype = C.c_ulong
     L.y2h_tail_launches.restype = C.c_ulong
     L.y2h_xcd_order_launches.restype = C.c_ulong
+    L.y2h_f32_stream_k_launches.restype = C.c_ulong
     _lib = L
     return L
 

@@ -101,6 +101,51 @@ def test_f32_tile_split_k_is_exact(oracle, workdir, monkeypatch, tile, pool):
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("wgs", [23, 18, 20, 64, 200])
+@pytest.mark.parametrize("tile", [(192, 256), (128, 128)], ids=lambda t: "%dx%d" % t)
+def test_f32_stream_k_is_exact(oracle, workdir, monkeypatch, tile, wgs, pool):
+    """conv_mfma_kernel<..., SKM> forced (Y2_SKF_WGS): the K loops of ALL output tiles (12 of 192x256, 18 of 128x128; 27 K-steps
+    each) dealt in equal contiguous shares to `wgs` workgroups -- shares that straddle tile boundaries (23), whole tiles (18
+    on the 128x128 tile), shares of a few K-steps (64, 200: several workgroups per tile) -- raw sums to tile-local piece
+    slots, sk_reduce_kernel adds a tile's pieces in K order, pools and applies the epilogue.  Exact against the oracle on
+    integer data (convolutional_layer.c:435-474, gemm.c:74-88, maxpool_layer.c:79-114)"""
+    bm, bn = tile
+    size = 20 if pool else 19
+    tiles = -(-3 * size * size // bm) * -(-(bn + 24) // bn)
+    if tiles > wgs:
+        pytest.skip("a share may not exceed one tile: %d tiles on %d workgroups" % (tiles, wgs))
+    monkeypatch.setenv("Y2_SKF_WGS", str(wgs))
+    before = darknet.lib().y2h_f32_stream_k_launches()
+    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=96, filters=bn + 24, ksize=3, size=20 if pool else 19, batch=3,
+                             tile=tile, pool=pool, ksplit=0, seed=5200 + bm + bn + pool + wgs)
+    assert name == "conv_mfma_f32_%dx%dx32_k3%s" % (bm, bn, "+maxpool2" if pool else ""), name
+    assert darknet.lib().y2h_f32_stream_k_launches() > before
+    assert np.array_equal(out, ref)
+
+
+def test_f32_stream_k_with_batchnorm_leaky_equals_split_k(oracle, workdir, monkeypatch):
+    """the reduce pass runs the reference's epilogue arithmetic (epilogue_f32 / pool_pick) like splitk_reduce_kernel: on
+    integer data, batch-norm + leaky with negative scales, the same bits as the integer split"""
+    outs = []
+    for mode in ("sk", "split"):
+        if mode == "sk":
+            monkeypatch.setenv("Y2_SKF_WGS", "23")
+        else:
+            monkeypatch.delenv("Y2_SKF_WGS", raising=False)
+            monkeypatch.setenv("Y2_SKF", "0")
+        spec = [("conv", 96, 3, 0, "linear"), ("conv", 152, 3, 1, "leaky"), ("max", 2, 2)]
+        cfg, wts, x = _small_int_conv_case(workdir, spec, 20, 3, 5300, neg_scale=True)
+        monkeypatch.setenv("Y2_CONV_TILE", "128x128")
+        monkeypatch.setenv("Y2_CONV_KSPLIT", "0" if mode == "sk" else "3")
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        outs.append(net.network_predict(x).copy())
+        net.free()
+    assert np.array_equal(outs[0], outs[1])
+    assert (outs[0] < 0).any() and (outs[0] > 0).any()
+
+
 @pytest.mark.parametrize("tile", [(192, 256), (128, 128), (64, 64)], ids=lambda t: "%dx%d" % t)
 def test_f32_split_k_scalar_store_fallback_is_exact(oracle, workdir, monkeypatch, tile):
     """a filter count that is no multiple of 4: the partial sums take the scalar store path instead of the 16-byte one"""
