@@ -670,8 +670,11 @@ __global__ __launch_bounds__(256) void sk_reduce_kernel(ConvK a, int bm, int bn,
 // whole kernel, and issues 14 v_mfma_f32_32x32x2_f32 per tile.  The next
 // tile's loads are in flight while the current one is multiplied.
 // ---------------------------------------------------------------------------
+#ifndef Y2_FIRST_MINB
+#define Y2_FIRST_MINB 1
+#endif
 template <int NT>
-__global__ __launch_bounds__(256) void conv_first_kernel(ConvK a)
+__global__ __launch_bounds__(256, Y2_FIRST_MINB) void conv_first_kernel(ConvK a)
 {
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
