@@ -65,8 +65,8 @@ THRESH, NMS = 0.2, 0.4             # Detector defaults (yolo_v2_class.hpp:45,50)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)      # >= 50 timed batches (the driver passes its own K / W)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="yolo608_b32", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-iters", type=int, default=3,
                     help="timed CPU-baseline forwards per leg, median reported (0 disables the CPU legs)")
@@ -727,6 +727,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "host_input": host, "map_equiv_vs_cpu": equiv, "latency": latency,
             "kernels_ms_per_step": {k: round(v / max(args.steps, 1), 3) for k, v in sorted(per_kernel_ms.items())},
             "device": darknet.device_name(),
+            # what this box's silicon does: the clock it holds under a full-chip fp32 matrix load (in-kernel stamps, measured
+            # right after the timed region); lines of different boxes differ by this much before any code does
+            "mfma_f32_clock_ghz": round(darknet.clock_probe(), 3),
         }
         print(json.dumps(line))
         sys.stdout.flush()

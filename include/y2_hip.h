@@ -83,6 +83,9 @@ int         y2h_stream_create(y2h_stream *s);
 int         y2h_stream_destroy(y2h_stream s);
 int         y2h_stream_sync(y2h_stream s);
 int         y2h_device_sync(void);
+/* the clock (GHz) this device holds under a full-chip fp32 matrix load: `iters` x 2 v_mfma_f32_32x32x2_f32 per wave on
+ * every CU, in-kernel s_memtime / s_memrealtime stamps, median over waves (diagnostic: benchmark lines quote it) */
+int         y2h_clock_probe(int iters, float *ghz, y2h_stream s);
 int         y2h_event_create(y2h_event *e);
 int         y2h_event_destroy(y2h_event e);
 int         y2h_event_record(y2h_event e, y2h_stream s);

@@ -322,3 +322,64 @@ extern "C" int y2h_copy_channels(const float *src, int ld_src, float *dst, int l
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Clock probe: what clock does THIS device hold under a full-chip fp32 matrix load?  Boxes of the pool differ by several
+// per cent in every number (power cap, silicon); the benchmark line carries this figure so that two lines can be compared.
+// One workgroup per CU slot, four waves each issuing `iters` dependent-free v_mfma_f32_32x32x2_f32 back to back (the
+// instruction of the dominant kernel); every wave stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its
+// loop.  Returns the median over waves of cycles / (ticks * 10 ns), in GHz.  Diagnostic only: nothing reads the values
+// on the device, no output of the engine depends on them.
+// ---------------------------------------------------------------------------
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *out, int iters, float seed)
+{
+    probe_f32x16 acc0, acc1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = seed * r; acc1[r] = seed + r; }
+    const float a = seed + threadIdx.x * 1e-3f, b = 1.0f - 1e-6f * threadIdx.x;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sink = 0.f;
+    for (int r = 0; r < 16; ++r) sink += acc0[r] + acc1[r];
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        out[2 * wave] = c1 - c0;
+        out[2 * wave + 1] = (r1 - r0) | (sink == 12345.678f ? 1ull << 62 : 0ull);      // keeps the loop alive
+    }
+}
+
+extern "C" int y2h_clock_probe(int iters, float *ghz, y2h_stream s)
+{
+    if (!ghz || iters <= 0) return Y2H_EINVAL;
+    const int blocks = 256, waves = blocks * 4;
+    unsigned long long *d = nullptr;
+    Y2H_CHECK(hipMalloc((void **)&d, (size_t)waves * 2 * sizeof(unsigned long long)));
+    // the clock governor needs a sustained load to settle (a single 0.5 ms launch reads 2.15 GHz from idle and 2.41 GHz right
+    // behind a benchmark loop on the same box): ~0.6 s of back-to-back launches, the LAST one is the measurement
+    const double launch_ms = (double)iters * 2.0 * 64.0 / 2.2e6;             // two MFMAs of 64 cycles per iteration at ~2.2 GHz
+    int reps = (int)(600.0 / (launch_ms > 0.01 ? launch_ms : 0.01));
+    if (reps < 2) reps = 2;
+    if (reps > 5000) reps = 5000;
+    for (int rep = 0; rep < reps; ++rep) {
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, S(s), d, iters, 0.5f);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(d); return Y2H_EHIP; }
+    }
+    std::vector<unsigned long long> h((size_t)waves * 2);
+    hipError_t e = hipStreamSynchronize(S(s));
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) { y2h_set_error_("clock probe", hipGetErrorString(e)); return Y2H_EHIP; }
+    std::vector<double> g;
+    for (int w = 0; w < waves; ++w) {
+        const double ticks = (double)(h[2 * w + 1] & ((1ull << 62) - 1));
+        if (ticks > 0) g.push_back((double)h[2 * w] / (ticks * 10.0));      // cycles per ns = GHz
+    }
+    if (g.empty()) return Y2H_EHIP;
+    std::sort(g.begin(), g.end());
+    *ghz = (float)g[g.size() / 2];
+    return Y2H_OK;
+}

@@ -224,6 +224,7 @@ def lib():
     L.y2h_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     L.y2h_device_count.restype = C.c_int
     L.y2h_device_name.restype = C.c_char_p
+    L.y2h_clock_probe.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_void_p]
     L.y2h_device_pci_bus_id.restype = C.c_char_p
     L.y2h_device_pci_bus_id.argtypes = [C.c_int]
     L.y2h_last_error.restype = C.c_char_p
@@ -836,6 +837,14 @@ def device_count() -> int:
 
 def device_name() -> str:
     return lib().y2h_device_name().decode()
+
+
+def clock_probe(iters: int = 8000) -> float:
+    """GHz the current device holds under a full-chip fp32 matrix load (y2h_clock_probe)"""
+    g = C.c_float(0)
+    if lib().y2h_clock_probe(iters, C.byref(g), None) != 0:
+        raise Y2Error("y2h_clock_probe: " + lib().y2h_last_error().decode())
+    return float(g.value)
 
 
 def device_pci_bus_id(dev: int = -1) -> str:
