@@ -294,13 +294,13 @@ int y2h_region_boxes(const y2h_decode *d, y2h_stream s);
 int y2h_nms_sort(const float *boxes, const float *probs_in, float *probs, int batch, int total, int classes,
                  int stride, float thresh, int *class_counts, y2h_stream s);
 /* The chain get_region_boxes -> do_nms_sort -> compaction of a plain region head (no tree, no map, <= 256 classes) in three
- * launches: y2h_region_boxes + y2h_nms_sort (nms > 0) + y2h_collect with the same results (region_layer.c:328-379,
+ * (four for more than a million scores) launches: y2h_region_boxes + y2h_nms_sort (nms > 0) + y2h_collect with the same results (region_layer.c:328-379,
  * box.c:249-277, yolo_v2_class.cpp:221-238).  q->thresh is both the decode and the collect threshold.  `probs_nms` is the
  * copy the NMS suppresses in (the final scores when nms > 0; q->probs keeps the unsuppressed ones), `class_counts` is
  * batch * classes ints that must be zero on entry and are zero again on return.  y2h_detect_chain_ok: 1 if `q` qualifies. */
 int y2h_detect_chain_ok(const y2h_decode *q);
 int y2h_detect_chain(const y2h_decode *q, float nms, float *probs_nms, int *class_counts, float *records, int *counts,
-                     int max_per_image, y2h_stream s);
+                     int max_per_image, float *best_scratch /* 2 * batch * w*h*num floats, as y2h_collect, or 0 */, y2h_stream s);
 /* class-agnostic variant, box.c:279-298 */
 int y2h_nms(const float *boxes, float *probs, int batch, int total, int classes, int stride,
             float thresh, y2h_stream s);

@@ -321,7 +321,7 @@ static int detect_enqueue(network net, float *d_pred, float thresh, float nms, i
             HIPCALL_I(y2h_memset(e->d_class_counts, 0, (size_t)net.batch * l->classes * sizeof(int), ds));
             e->class_counts_zeroed = 1;
         }
-        HIPCALL_I(y2h_detect_chain(&q, nms, e->d_probs_nms, e->d_class_counts, e->d_records, e->d_counts, e->det_cap, ds));
+        HIPCALL_I(y2h_detect_chain(&q, nms, e->d_probs_nms, e->d_class_counts, e->d_records, e->d_counts, e->det_cap, e->d_best, ds));
         goto fetch;
     }
     HIPCALL_I(y2h_region_boxes(&q, ds));
