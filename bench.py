@@ -88,6 +88,8 @@ def parse_args():
     ap.add_argument("--latency-iters", type=int, default=200,
                     help="calls per entry of the batch-1 latency block (test_detector_img / Detector::detect on tiny-yolo-voc and "
                          "yolo at 416; N=1 only; 0 disables)")
+    ap.add_argument("--clock-probe", type=int, default=1,
+                    help="0: skip the 0.6 s clock probe behind the timed region (profiling runs: its launches would fill the kernel trace)")
     ap.add_argument("--dump-dets", default=None, help="write each rank's last-batch detections to PATH.rank<r>.npz")
     return ap.parse_args()
 
@@ -729,7 +731,7 @@ def main():
             "device": darknet.device_name(),
             # what this box's silicon does: the clock it holds under a full-chip fp32 matrix load (in-kernel stamps, measured
             # right after the timed region); lines of different boxes differ by this much before any code does
-            "mfma_f32_clock_ghz": round(darknet.clock_probe(), 3),
+            "mfma_f32_clock_ghz": round(darknet.clock_probe(), 3) if args.clock_probe else None,
         }
         print(json.dumps(line))
         sys.stdout.flush()

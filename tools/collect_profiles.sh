@@ -10,7 +10,7 @@ set -uo pipefail
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 w=$1; tag=$2
 out=gpurun_out/prof_$tag; mkdir -p "$out"
-args="--workload $w --cpu-iters 0 --host-input off --autotune 0 --latency-iters 0"
+args="--workload $w --cpu-iters 0 --host-input off --autotune 0 --latency-iters 0 --clock-probe 0"
 rocprofv3 --kernel-trace --stats -f csv -d "$out/kt" -o kt -- python3 bench.py $args --steps 10 --warmup 3 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/kt.err" || { tail -5 "$out/kt.err"; exit 1; }
 find "$out/kt" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_kernel_stats.csv" \;
 export Y2_BENCH_DUMP_KERNELS=$PWD/$out/layer_kernels.json
