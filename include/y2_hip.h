@@ -178,6 +178,12 @@ unsigned long y2h_tail_launches(void);
 unsigned long y2h_xcd_order_launches(void);
 /* number of fp32 matrix-core launches that used stream-K work items (grids smaller than the machine) */
 unsigned long y2h_f32_stream_k_launches(void);
+/* number of fp32 matrix-core launches that cut their partial last round along K over all workgroups and finished the
+ * pieces inside the launch (hybrid stream-K: producer pieces publish raw sums write-through and raise a flag, the
+ * tile's last piece adds them and runs the epilogue; no second launch) */
+unsigned long y2h_f32_hybrid_stream_k_launches(void);
+/* flag waits of such launches that gave up after seconds (0 always, unless a workgroup was lost; synchronous read) */
+int y2h_f32_stream_k_timeouts(void);
 /* 1 when the shape fits the dedicated first-layer kernel (3 channels, 3x3/1 pad 1, <= 64
  * filters) provided the input is supplied with a halo (x_halo = 1) */
 int y2h_conv_first_layer_ok(const y2h_conv *d);

@@ -56,9 +56,12 @@
 // ---------------------------------------------------------------------------
 // MFMA implicit GEMM
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int BK, int KS, int WM, int WN, bool PIPE, bool XO = false, bool SKM = false>
+__device__ int g_skh_timeouts = 0;     // hybrid stream-K: flag waits that gave up (a bug or a lost workgroup; results of that launch are wrong)
+template <int BM, int BN, int BK, int KS, int WM, int WN, bool PIPE, bool XO = false, int SKMODE = 0>
 __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
 {
+    constexpr bool SKM = SKMODE == 1;     // stream-K over ALL tiles, pieces finished by sk_reduce_kernel (grids smaller than the machine)
+    constexpr bool SKH = SKMODE == 2;     // hybrid: whole tiles + the last partial round cut along K, finished inside this launch
     constexpr int NT = WM * WN * 64;
     constexpr int LS = BK + 4;            // LDS row stride (floats); (LS/4) odd -> conflict-free b128 reads
     constexpr int CH = BK / 4;            // 16-byte chunks per staged row
@@ -118,13 +121,37 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             if (k0 + len > nk) { sk_ke1 = k0 + len - nk; n_sk = 2; }
         }
     }
-    const int END = SKM ? 2 : a.ntiles;       // work-item number that means "past the end"
+    // SKH (hybrid stream-K, grids of several rounds: batch 32): the first ndp = ntiles - sk_tiles output tiles are walked whole
+    // (b, b + G, ...); the K loops of the last sk_tiles tiles -- the partial last round -- are dealt in equal contiguous
+    // shares to ALL G workgroups, again at most two pieces each.  A piece that does not reach the end of its tile's K loop
+    // ("producer"; at most one per workgroup) leaves its raw sums in slot wg and raises that slot's flag; the piece that does ("finisher")
+    // waits for the flags of the tile's earlier pieces, adds their sums to its accumulators and runs the ordinary epilogue.
+    // A workgroup computes its producer piece FIRST, then its finisher piece, then its whole tiles: no producer ever waits,
+    // so the hand-off cannot deadlock (workgroups are dispatched in order: a finisher's producers, all lower-numbered,
+    // are on the machine before it), and by the time a finisher has computed its own piece its producers, who started at the
+    // same moment with a piece no longer than the finisher's share, have published.  Work-item codes in SKH: 0 .. ndp - 1 a
+    // whole tile, ntiles + v piece v of this workgroup (v = 0: in tile sk_t0, from sk_kb0; v = 1: the head of tile sk_t0 + 1).
+    const int ndp = SKH ? a.ntiles - a.sk_tiles : 0;
+    if constexpr (SKH) {
+        const long I = (long)a.sk_tiles * nk;
+        const long lo = (long)blockIdx.x * I / a.sk_wgs, hi = (long)(blockIdx.x + 1) * I / a.sk_wgs;
+        if (hi > lo) {
+            const int t0 = (int)(lo / nk), k0 = (int)(lo - (long)t0 * nk), len = (int)(hi - lo);
+            sk_t0 = ndp + t0; sk_kb0 = k0; sk_ke0 = k0 + len < nk ? k0 + len : nk; n_sk = 1;
+            if (k0 + len > nk) { sk_ke1 = k0 + len - nk; n_sk = 2; }
+        }
+    }
+    const int END = SKM ? 2 : SKH ? a.ntiles + 2 : a.ntiles;       // work-item number that means "past the end"
     auto setup_tile = [&](int vtile) {
     const bool live = vtile < END;
-    const int tile = SKM ? sk_t0 + (vtile & 1) : vtile / a.ksplit;
-    const int kb = SKM ? (vtile == 0 ? sk_kb0 : 0) : ((vtile - tile * a.ksplit) * nk) / a.ksplit;     // first slice of this work item
+    const bool piece = SKH && vtile >= a.ntiles;                   // (SKH) a stream-K piece of this workgroup
+    const int tile = SKM ? sk_t0 + (vtile & 1) : piece ? sk_t0 + (vtile - a.ntiles) : vtile / a.ksplit;
+    const int kb = SKM ? (vtile == 0 ? sk_kb0 : 0)
+                 : SKH ? (piece && vtile == a.ntiles ? sk_kb0 : 0)
+                       : ((vtile - tile * a.ksplit) * nk) / a.ksplit;     // first slice of this work item
     s_n = !live ? 0x40000000                                                                       // past the end: never hop again
           : SKM ? (vtile == 0 ? sk_ke0 - sk_kb0 : sk_ke1)
+          : SKH ? (!piece ? nk : vtile == a.ntiles ? sk_ke0 - sk_kb0 : sk_ke1)
                 : (((vtile - tile * a.ksplit) + 1) * nk) / a.ksplit - kb;
     c0 = (kb / (KS * KS)) * BK;
     tap = kb % (KS * KS);
@@ -209,6 +236,11 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
             return (pb * a.pblk + pi) * a.tiles_n + xcd + 8 * fi;
         }
         if constexpr (SKM) return i < n_sk ? i : END;
+        if constexpr (SKH) {
+            if (i < n_sk) return a.ntiles + (n_sk == 2 ? 1 - i : 0);          // the producer piece (head of the next tile) first
+            const long tl = (long)blockIdx.x + (long)(i - n_sk) * gridDim.x;
+            return tl < ndp ? (int)tl : END;
+        }
         const long tl = (long)wgid + (long)i * gridDim.x;
         return tl < a.ntiles ? (int)tl : a.ntiles;
     };
@@ -303,7 +335,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     int cur = 0;
 #ifdef Y2_F32_STAMPS
     // diagnostic: cycles per wave in [0] tile setup + accumulator clear, [1] K loop, [2] epilogue; [3] K-steps, [4] tiles
-    unsigned long long st[5] = {0, 0, 0, 0, 0}, st_bar = 0, st_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long st[7] = {0, 0, 0, 0, 0, 0, 0}, st_bar = 0, st_prev = __builtin_amdgcn_s_memtime();      // [5] producer publish, [6] finisher wait + gather (hybrid stream-K)
 #define F32_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[k] += t_ - st_prev; st_prev = t_; } while (0)
 #else
 #define F32_STAMP(k) do { } while (0)
@@ -311,9 +343,20 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     for (int cti = 0;; ++cti) {
     const int vt = tile_at(cti);
     if (vt >= END) break;
-    const int ct = SKM ? sk_t0 + vt : vt / a.ksplit, ks = SKM ? 2 * (int)blockIdx.x + vt : vt - ct * a.ksplit;       // SKM: ks = piece slot
-    const int kb = SKM ? (vt == 0 ? sk_kb0 : 0) : (ks * nk) / a.ksplit, ke = SKM ? (vt == 0 ? sk_ke0 : sk_ke1) : ((ks + 1) * nk) / a.ksplit;
+    const bool piece = SKH && vt >= a.ntiles;
+    const int ct = SKM ? sk_t0 + vt : piece ? sk_t0 + (vt - a.ntiles) : vt / a.ksplit;
+    const int ks = SKM ? 2 * (int)blockIdx.x + vt : piece ? (int)blockIdx.x : vt - ct * a.ksplit;       // SKM: piece slot; SKH: a workgroup has at most ONE producer piece, slot = workgroup
+    const int kb = SKM ? (vt == 0 ? sk_kb0 : 0) : SKH ? (piece && vt == a.ntiles ? sk_kb0 : 0) : (ks * nk) / a.ksplit;
+    const int ke = SKM ? (vt == 0 ? sk_ke0 : sk_ke1) : SKH ? (!piece ? nk : vt == a.ntiles ? sk_ke0 : sk_ke1) : ((ks + 1) * nk) / a.ksplit;
     const int p0 = (ct / a.tiles_n) * BM, n0 = (ct % a.tiles_n) * BN;
+    if constexpr (SKH) {
+        // Every vector-memory operation retired before a work item starts, as a wait the compiler's waitcnt pass SEES (an asm
+        // wait is invisible to it): otherwise a register reload issued in front of the tile loop stays "pending" in the pass's
+        // merged state at the K loop's header, and the K-step opens with vmcnt(4) / vmcnt(0) -- the slice loads issued under
+        // the previous step's last MFMA group get 1 300 cycles of cover instead of 4 500 (K-step 12.8 k -> 16.2 k cycles).
+        // Costs the tail of the previous item's stores once per work item.
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) expcnt(7) lgkmcnt(15)
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -556,6 +599,69 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
+    if constexpr (SKH) {
+        constexpr int NE = TM * TN * 4;                   // 16-byte groups of accumulators per lane
+        if (piece && ke < nk) {
+            // producer: the raw sums leave as the lanes hold them, NE coalesced 16-byte write-through (sc1) stores per lane into
+            // [slot][e][thread]; every wave drains its stores, then ONE lane raises the flag (MI355X hand-off rules: sc1 payload,
+            // vmcnt(0) in asm -- the compiler may drop a waitcnt it thinks redundant --, sc1 flag)
+            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ws + (size_t)ks * (BM * BN)), 0, (unsigned)(BM * BN * 4), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), pr, (unsigned)((((i * TN + j) * 4 + q) * NT + t) * 16), 0, 16);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t == 0) __hip_atomic_store(a.sk_flags + ks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            F32_STAMP(5);
+            continue;
+        }
+        if (piece && kb > 0) {
+            // finisher: the earlier pieces of this tile belong to the workgroups below this one whose shares reach into it
+            const long I = (long)a.sk_tiles * nk, G = a.sk_wgs, tb = (long)(ct - ndp) * nk;
+            long w0 = tb * G / I;
+            while (w0 > 0 && w0 * I / G > tb) --w0;
+            while (w0 + 1 < G && (w0 + 1) * I / G <= tb) ++w0;
+            if (t == 0) {
+                for (long w = w0; w < (long)blockIdx.x; ++w) {
+                    const long lo = w * I / G, hi = (w + 1) * I / G;
+                    if (hi <= lo) continue;
+                    int *fl = a.sk_flags + w;
+                    int spins = 0;
+                    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                        if (++spins > (1 << 22)) { atomicAdd(&g_skh_timeouts, 1); break; }        // seconds: counted (y2h_f32_stream_k_timeouts), never a hang
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the polling lane's last load has returned; see above)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");                          // no payload load may be scheduled in front of the barrier
+            for (long w = w0; w < (long)blockIdx.x; ++w) {
+                const long lo = w * I / G, hi = (w + 1) * I / G;
+                if (hi <= lo) continue;
+                const size_t slot = (size_t)w;
+                const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.ws + slot * (BM * BN)), 0, (unsigned)(BM * BN * 4), 0x00020000);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, (unsigned)((((i * TN + j) * 4 + q) * NT + t) * 16), 0, 16));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+                        }
+            }
+            F32_STAMP(6);
+        }
+    }
     if (SKM || (a.ksplit > 1 && (a.Cout & 3) == 0)) {
         partial_pass();
         if (!ES_OWN) {
@@ -577,7 +683,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void conv_mfma_kernel(ConvK a)
     }   // tile loop
 #ifdef Y2_F32_STAMPS
     if (lane == 0 && a.stamps)
-        for (int k = 0; k < 5; ++k) a.stamps[((size_t)blockIdx.x * (NT / 64) + wv) * 5 + k] = (k == 0) ? st_bar : st[k];      // [0]: barrier wait (setup dropped)
+        for (int k = 0; k < 7; ++k) a.stamps[((size_t)blockIdx.x * (NT / 64) + wv) * 7 + k] = (k == 0) ? st_bar : st[k];      // [0]: barrier wait (setup dropped)
 #endif
 }
 
@@ -1241,19 +1347,21 @@ struct Variant {
     bool attr_set_xo[16];
     void (*fn_sk)(ConvK);  // the same tile with stream-K work items (ConvK.sk_tiles / sk_wgs), where instantiated
     bool attr_set_sk[16];
+    void (*fn_skh)(ConvK); // the same tile, hybrid: whole tiles + the last partial round as stream-K pieces finished in the launch
+    bool attr_set_skh[16];
 };
 
 #define VAR(BM, BN, BK, KS, WM, WN)                                                             \
     { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
-      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, nullptr, {false}, nullptr, {false} }
+      (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, nullptr, {false}, nullptr, {false}, nullptr, {false} }
 #define VARSK(BM, BN, BK, KS, WM, WN)                                                           \
     { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
       (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, \
-      nullptr, {false}, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, false, true>, {false} }
+      nullptr, {false}, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, false, 1>, {false}, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, false, 2>, {false} }
 #define VARXO(BM, BN, BK, KS, WM, WN)                                                           \
     { "conv_mfma_f32_" #BM "x" #BN "x" #BK "_k" #KS, BM, BN, BK, KS, conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE>, \
       (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float) + (WM * WN == 8 ? (size_t)8 * 16 * 36 * sizeof(float) : 0), WM * WN * 64, {false}, \
-      conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, true>, {false}, nullptr, {false} }
+      conv_mfma_kernel<BM, BN, BK, KS, WM, WN, Y2_PIPE, true>, {false}, nullptr, {false}, nullptr, {false} }
 
 #ifndef Y2_PIPE
 #define Y2_PIPE true
@@ -1280,6 +1388,23 @@ static Variant g_variants[] = {
 
 static unsigned long g_xcd_order_launches = 0;
 extern "C" unsigned long y2h_xcd_order_launches(void) { return g_xcd_order_launches; }
+
+#ifdef Y2_F32_STAMPS
+static void f32_stamps_report(const Variant *v, const y2h_conv *d, long grid, unsigned long long *d_st, y2h_stream s)
+{
+    if (!getenv("Y2_F32_STAMPS")) return;
+    static unsigned long long h[1024 * 8 * 7];
+    if (hipStreamSynchronize(S(s)) != hipSuccess || hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+    double tot[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int waves = v->threads / 64;
+    for (long b = 0; b < grid; ++b) for (int w = 0; w < waves; ++w) for (int k = 0; k < 7; ++k) tot[k] += (double)h[(b * waves + w) * 7 + k];
+    const double tiles = tot[4] > 0 ? tot[4] : 1, steps = tot[3] > 0 ? tot[3] : 1, nw = (double)grid * waves;
+    fprintf(stderr, "f32 stamps %s %dx%d c%d n%d: per wave: K-step %.0f cycles of which %.0f at the barrier (%.1f steps per work item), epilogue %.0f per work item; "
+            "per wave and launch: K loop %.0f, epilogue %.0f, publish %.0f, wait+gather %.0f kcycles\n",
+            v->name, d->h, d->w, d->c, d->n, tot[1] / steps, tot[0] / steps, steps / tiles, tot[2] / tiles, tot[1] / nw / 1e3, tot[2] / nw / 1e3,
+            tot[5] / nw / 1e3, tot[6] / nw / 1e3);
+}
+#endif
 
 static bool mfma_ok(const y2h_conv *d)
 {
@@ -1321,7 +1446,52 @@ extern "C" unsigned long y2h_f32_stream_k_launches(void) { return g_skf_launches
 
 // sk_wgs_out (optional): > 0 when the choice is the stream-K form of the tile (conv_mfma_kernel<..., SKM>) on that many
 // workgroups -- then *ksplit_out is 1.  Env: Y2_SKF=0 off; Y2_SKF_WGS=n forces stream-K on n workgroups for the (forced) tile.
-static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr, int *sk_wgs_out = nullptr)
+// Hybrid stream-K plan (conv_mfma_kernel<..., 2>): of `tiles` output tiles of nk K-steps on `slots` co-resident workgroups, how
+// many tiles of the last, partial round are cut along K over all the workgroups (0 = none).  In microseconds of one CU:
+// the partial round costs a whole tile time whatever it holds; cut, every workgroup gets R / slots of a tile plus a second
+// work item's fixed cost, one 16-byte-store pass of its accumulators, one read pass per earlier piece of the tile it
+// finishes, and the launch pays a flag memset.  OFF by default: measured in the benchmark's own context (yolo.cfg 608 b32, four
+// interleaved runs, profiles/r03_notes.md section 9) the hybrid instantiation's K loop comes out of the compiler 2.5 % of a
+// step slower than the plain one (the kernel sits at the 256-register ceiling; the extra scalar state moves the fragment
+// reads of the software pipeline) and cutting the partial rounds wins back 1.2 %.  Env Y2_SKH=1 whenever a partial round
+// exists (tests), 2 by the cost model below.
+static unsigned long g_skh_launches = 0;
+extern "C" unsigned long y2h_f32_hybrid_stream_k_launches(void) { return g_skh_launches; }
+extern "C" int y2h_f32_stream_k_timeouts(void)
+{
+    int n = -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_skh_timeouts), sizeof n) != hipSuccess) return -1;
+    return n;
+}
+static int skh_plan(long tiles, int nk, long slots, int bm, int bn, int bk, int bpc)
+{
+    int mode = 0;
+    if (const char *f = getenv("Y2_SKH")) mode = atoi(f);
+    if (mode <= 0 || tiles < 1 || slots < 2) return 0;
+    const long R = tiles < slots ? tiles : tiles % slots;
+    if (R == 0) return 0;
+    const long share = R * nk / slots;
+    if (share < 4) return 0;
+    if (mode == 1) return (int)R;
+    const double kstep_us = (double)bm * bn * bk / 128.0 * bpc / 2400.0;
+    const double piece_us = (double)bm * bn * 4.0 / 65e3;                       // one slot at ~65 GB/s per workgroup (cross-XCD hand-off read)
+    const double gain = (1.0 - (double)R / slots) * (nk + 1.2) * kstep_us;
+    const double cost = 1.6 * kstep_us + piece_us + piece_us * (double)((slots + R - 1) / R) + 4.0;
+    return gain > 1.3 * cost ? (int)R : 0;
+}
+
+static long skh_slots(const Variant &v)      // workgroups of a hybrid stream-K launch: all that are co-resident (Y2_SKH_WGS=n: tests, small shapes)
+{
+    if (const char *f = getenv("Y2_SKH_WGS")) { if (atol(f) >= 2 && atol(f) <= 256L * variant_bpc(v)) return atol(f); }
+    return 256L * variant_bpc(v);
+}
+static size_t skh_ws_bytes(const Variant &v)
+{
+    const size_t wgs = (size_t)skh_slots(v);
+    return wgs * v.bm * v.bn * sizeof(float) + wgs * sizeof(int);
+}
+
+static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr, int *sk_wgs_out = nullptr, int *skh_tiles_out = nullptr)
 {
     const int bk = (d->c % 32 == 0) ? 32 : 16;
     const long npix = (long)d->batch * d->out_h * d->out_w;
@@ -1401,6 +1571,14 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr, int *
     }
     if (ksplit_out) *ksplit_out = best_split;
     if (sk_wgs_out) *sk_wgs_out = best_sk;
+    if (skh_tiles_out) {
+        *skh_tiles_out = 0;
+        if (best && best->fn_skh && best_sk == 0 && best_split == 1 && !getenv("Y2_CONV_GRID")) {
+            const long tiles = ((npix + best->bm - 1) / best->bm) * ((d->n + best->bn - 1) / best->bn);
+            const int bpc = variant_bpc(*best);
+            *skh_tiles_out = skh_plan(tiles, nk, skh_slots(*best), best->bm, best->bn, best->bk, bpc);
+        }
+    }
     return best;
 }
 
@@ -1446,10 +1624,11 @@ extern "C" size_t y2h_conv_workspace_bytes(const y2h_conv *d)
     int ksplit = 1;
     if (d->x_f16 && !d->x_halo) return y2_f16_conv_workspace_bytes(d);      // stream-K piece slots of the fp16 256x256 kernel
     if (c32_f32_ok(d)) return 0;
-    int sk_wgs = 0;
-    Variant *v = (d->x_halo || d->x_f16 || !mfma_ok(d)) ? nullptr : pick_variant(d, &ksplit, &sk_wgs);
+    int sk_wgs = 0, skh_tiles = 0;
+    Variant *v = (d->x_halo || d->x_f16 || !mfma_ok(d)) ? nullptr : pick_variant(d, &ksplit, &sk_wgs, &skh_tiles);
     if (!v) return 0;
     if (sk_wgs > 0) return (size_t)2 * sk_wgs * v->bm * v->bn * sizeof(float);          // stream-K piece slots
+    if (skh_tiles > 0) return skh_ws_bytes(*v);                                          // one slot and one flag per workgroup
     if (ksplit <= 1) return 0;
     return (size_t)ksplit * d->batch * d->out_h * d->out_w * d->n * sizeof(float);
 }
@@ -1612,8 +1791,9 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
     }
     if (!strict && y2_f16_conv_ok(d)) return y2_f16_conv_launch(d, a, s);
     if (!strict && c32_f32_ok(d)) return c32_f32_launch(d, a, s);
-    int ksplit = 1, sk_wgs = 0;
-    Variant *v = (!strict && d->x_halo == 0 && mfma_ok(d)) ? pick_variant(d, &ksplit, &sk_wgs) : nullptr;
+    int ksplit = 1, sk_wgs = 0, skh_tiles = 0;
+    Variant *v = (!strict && d->x_halo == 0 && mfma_ok(d)) ? pick_variant(d, &ksplit, &sk_wgs, &skh_tiles) : nullptr;
+    if (v && skh_tiles > 0 && (!d->ws || d->ws_bytes < skh_ws_bytes(*v) || ((uintptr_t)d->ws % 16) != 0)) skh_tiles = 0;      // no room: every tile whole
     if (v && sk_wgs > 0 && (!d->ws || d->ws_bytes < (size_t)2 * sk_wgs * v->bm * v->bn * sizeof(float) || ((uintptr_t)d->y % 16) != 0 ||
                             ((uintptr_t)d->ws % 16) != 0)) {
         sk_wgs = 0;                                       // no room for the piece slots: the integer split of the same descriptor
@@ -1694,8 +1874,8 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         }
 #ifdef Y2_F32_STAMPS
         static unsigned long long *d_st = nullptr;
-        if (!d_st) Y2H_CHECK(hipMalloc((void **)&d_st, 1024 * 8 * 5 * sizeof(unsigned long long)));
-        Y2H_CHECK(hipMemsetAsync(d_st, 0, 1024 * 8 * 5 * sizeof(unsigned long long), S(s)));
+        if (!d_st) Y2H_CHECK(hipMalloc((void **)&d_st, 1024 * 8 * 7 * sizeof(unsigned long long)));
+        Y2H_CHECK(hipMemsetAsync(d_st, 0, 1024 * 8 * 7 * sizeof(unsigned long long), S(s)));
         a.stamps = d_st;
 #endif
         if (sk_wgs > 0) {
@@ -1718,6 +1898,26 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
             ++g_skf_launches;
             return Y2H_OK;
         }
+        if (skh_tiles > 0 && !a.xcd_order) {
+            // hybrid stream-K: the partial last round's K loops in equal shares over ALL co-resident workgroups, finished in-launch
+            const long wgs = skh_slots(*v);
+            a.sk_tiles = getenv("Y2_SKH_NOSPLIT") ? 0 : skh_tiles;      // (diagnostic: the hybrid instantiation walking every tile whole)
+            a.sk_wgs = (int)wgs;
+            a.ws = d->ws;
+            a.sk_flags = (int *)(d->ws + (size_t)wgs * v->bm * v->bn);
+            Y2H_CHECK(hipMemsetAsync(a.sk_flags, 0, (size_t)wgs * sizeof(int), S(s)));
+            if (dev < 0 || dev >= 16 || !v->attr_set_skh[dev]) {
+                Y2H_CHECK(hipFuncSetAttribute((const void *)v->fn_skh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds));
+                if (dev >= 0 && dev < 16) v->attr_set_skh[dev] = true;
+            }
+            hipLaunchKernelGGL(v->fn_skh, dim3((unsigned)wgs), dim3(v->threads), v->lds, S(s), a);
+            Y2H_LAUNCH_CHECK();
+            ++g_skh_launches;
+#ifdef Y2_F32_STAMPS
+            f32_stamps_report(v, d, wgs, d_st, s);
+#endif
+            return Y2H_OK;
+        }
         if (a.xcd_order) {
             ++g_xcd_order_launches;
             if (dev < 0 || dev >= 16 || !v->attr_set_xo[dev]) {
@@ -1730,17 +1930,7 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         }
         Y2H_LAUNCH_CHECK();
 #ifdef Y2_F32_STAMPS
-        if (getenv("Y2_F32_STAMPS")) {
-            static unsigned long long h[1024 * 8 * 5];
-            Y2H_CHECK(hipStreamSynchronize(S(s)));
-            Y2H_CHECK(hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost));
-            double tot[5] = {0, 0, 0, 0, 0};
-            const int waves = v->threads / 64;
-            for (long b = 0; b < grid; ++b) for (int w = 0; w < waves; ++w) for (int k = 0; k < 5; ++k) tot[k] += (double)h[(b * waves + w) * 5 + k];
-            const double tiles = tot[4] > 0 ? tot[4] : 1, steps = tot[3] > 0 ? tot[3] : 1;
-            fprintf(stderr, "f32 stamps %s %dx%d c%d n%d: per wave: K-step %.0f cycles of which %.0f at the barrier (%.1f steps per tile), epilogue %.0f per tile\n",
-                    v->name, d->h, d->w, d->c, d->n, tot[1] / steps, tot[0] / steps, steps / tiles, tot[2] / tiles);
-        }
+        f32_stamps_report(v, d, grid, d_st, s);
 #endif
         if (ksplit > 1) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(y2h_grid((long)a.npix * a.Cout, 256)), dim3(256), 0, S(s), a);

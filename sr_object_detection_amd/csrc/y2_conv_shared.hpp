@@ -37,6 +37,7 @@ struct ConvK {
     // each share is one or two pieces (tile, K range) whose raw fp32 sums go to slot 2*wg + piece of `ws`, and a fix-up
     // launch adds a tile's pieces in ascending K order and applies the epilogue.  0 = every tile is walked whole.
     int sk_tiles, sk_wgs;
+    int *sk_flags;     // hybrid stream-K of the fp32 kernel (conv_mfma_kernel<..., 2>): one flag per piece slot (2 * sk_wgs ints), zeroed before the launch
     // fp32 matrix-core kernel, wide heads (yolo9000's 28 269-filter 1x1: 116 MB of weights against 9.5 MB of input): tiles are
     // dealt per XCD -- workgroups b with the same b % 8 share an L2 -- so that XCD x owns filter tiles x, x + 8, ... (every
     // weight byte enters ONE L2) and walks them in blocks of `pblk` pixel tiles whose input rows stay L2-resident meanwhile.

@@ -240,6 +240,8 @@ def lib():
     L.y2h_tail_launches.restype = C.c_ulong
     L.y2h_xcd_order_launches.restype = C.c_ulong
     L.y2h_f32_stream_k_launches.restype = C.c_ulong
+    L.y2h_f32_hybrid_stream_k_launches.restype = C.c_ulong
+    L.y2h_f32_stream_k_timeouts.restype = C.c_int
     _lib = L
     return L
 

@@ -44,7 +44,10 @@ def _run(oracle, workdir, monkeypatch, *, cin, filters, ksize, size, batch, tile
         spec.append(("max", 2, 2))
     cfg, wts, x = _small_int_conv_case(workdir, spec, size, batch, 20000 + seed)
     monkeypatch.setenv("Y2_CONV_TILE", "%dx%d" % tile)
-    monkeypatch.setenv("Y2_CONV_GRID", str(grid))
+    if grid is None:
+        monkeypatch.delenv("Y2_CONV_GRID", raising=False)
+    else:
+        monkeypatch.setenv("Y2_CONV_GRID", str(grid))
     monkeypatch.setenv("Y2_CONV_KSPLIT", str(ksplit))
     if no_m16:
         monkeypatch.setenv("Y2_NO_M16", "1")
@@ -122,6 +125,59 @@ def test_f32_stream_k_is_exact(oracle, workdir, monkeypatch, tile, wgs, pool):
     assert name == "conv_mfma_f32_%dx%dx32_k3%s" % (bm, bn, "+maxpool2" if pool else ""), name
     assert darknet.lib().y2h_f32_stream_k_launches() > before
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("pool", [False, True], ids=["nopool", "pool"])
+@pytest.mark.parametrize("wgs", [5, 7, 16, 23, 40])
+@pytest.mark.parametrize("tile", [(192, 256), (128, 128)], ids=lambda t: "%dx%d" % t)
+def test_f32_hybrid_stream_k_is_exact(oracle, workdir, monkeypatch, tile, wgs, pool):
+    """conv_mfma_kernel<..., 2> forced (Y2_SKH=1 on Y2_SKH_WGS workgroups): whole tiles for the full rounds, the K loops of
+    the partial last round (12 tiles of 192x256 / 18 of 128x128, 27 K-steps each) in equal shares over ALL the workgroups
+    -- 5: two tiles over five workgroups (a middle piece, a workgroup with a finisher and a producer piece); 7 / 16: shares
+    of most of a tile; 23 / 40: fewer tiles than workgroups, every tile cut, up to four pieces per tile -- producers
+    publish raw sums write-through and raise a flag, the piece that ends a tile's K loop adds them and runs the ordinary
+    epilogue inside the same launch.  Exact against the oracle on integer data (convolutional_layer.c:435-474,
+    gemm.c:74-88, maxpool_layer.c:79-114); no flag wait may time out"""
+    bm, bn = tile
+    size = 20 if pool else 19
+    tiles = -(-3 * size * size // bm) * -(-(bn + 24) // bn)
+    rest = tiles if tiles < wgs else tiles % wgs
+    if rest * 27 // wgs < 4:
+        pytest.skip("no partial round worth cutting: %d tiles on %d workgroups" % (tiles, wgs))
+    monkeypatch.setenv("Y2_SKH", "1")
+    monkeypatch.setenv("Y2_SKH_WGS", str(wgs))
+    monkeypatch.setenv("Y2_SKF", "0")
+    L = darknet.lib()
+    before = L.y2h_f32_hybrid_stream_k_launches()
+    out, ref, name, _ = _run(oracle, workdir, monkeypatch, cin=96, filters=bn + 24, ksize=3, size=size, batch=3,
+                             tile=tile, pool=pool, ksplit=1, grid=None, seed=5600 + bm + bn + pool + wgs)
+    assert name == "conv_mfma_f32_%dx%dx32_k3%s" % (bm, bn, "+maxpool2" if pool else ""), name
+    assert L.y2h_f32_hybrid_stream_k_launches() > before
+    assert L.y2h_f32_stream_k_timeouts() == 0
+    assert np.array_equal(out, ref)
+
+
+def test_f32_hybrid_stream_k_with_batchnorm_leaky_equals_whole_tiles(oracle, workdir, monkeypatch):
+    """the finisher piece runs the kernel's own epilogue: batch-norm + leaky with negative scales and a fused maxpool give the
+    same bits as the launch that walks every tile whole (integer data: the sums are exact in any order)"""
+    outs = []
+    for mode in ("skh", "whole"):
+        monkeypatch.setenv("Y2_SKH", "1" if mode == "skh" else "0")
+        monkeypatch.setenv("Y2_SKH_WGS", "5")
+        monkeypatch.setenv("Y2_SKF", "0")
+        spec = [("conv", 96, 3, 0, "linear"), ("conv", 280, 3, 1, "leaky"), ("max", 2, 2)]
+        cfg, wts, x = _small_int_conv_case(workdir, spec, 20, 3, 5700, neg_scale=True)
+        monkeypatch.setenv("Y2_CONV_TILE", "192x256")
+        monkeypatch.setenv("Y2_CONV_KSPLIT", "1")
+        monkeypatch.delenv("Y2_CONV_GRID", raising=False)
+        before = darknet.lib().y2h_f32_hybrid_stream_k_launches()
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        outs.append(net.network_predict(x).copy())
+        net.free()
+        assert (darknet.lib().y2h_f32_hybrid_stream_k_launches() > before) == (mode == "skh")
+    assert np.array_equal(outs[0], outs[1])
+    assert (outs[0] < 0).any() and (outs[0] > 0).any()
 
 
 def test_f32_stream_k_with_batchnorm_leaky_equals_split_k(oracle, workdir, monkeypatch):
