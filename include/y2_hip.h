@@ -266,6 +266,15 @@ int y2h_f16_to_f32(const void *src, float *dst, long n, y2h_stream s);
  * (group_size/group_offset device arrays, groups>0) on the class scores. */
 int y2h_region_forward(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
                        int softmax, int groups, const int *group_size, const int *group_offset, y2h_stream s);
+/* The same for a tree head, plus -- from the class row still in LDS -- what get_region_boxes needs of it in detect mode
+ * (region_layer.c:351-367 without a map; tree.c:37-44): best[0 .. boxes) = hierarchy probability of the deepest class above
+ * .5 (0: none), best[boxes .. 2 boxes) = that class as int.  Independent of the detection threshold; y is written exactly
+ * as by y2h_region_forward.  parent / order / level_off / levels: the tree with its nodes listed by depth level (parents
+ * precede children).  y2h_region_tree_best_ok: 1 when the row fits the LDS kernel. */
+int y2h_region_tree_best_ok(int classes, int levels);
+int y2h_region_forward_tree_best(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
+                                 int groups, const int *group_size, const int *group_offset, const int *parent,
+                                 const int *order, const int *level_off, int levels, float *best, y2h_stream s);
 
 typedef struct y2h_decode {
     int batch, w, h, num, classes;
@@ -307,6 +316,16 @@ int y2h_nms_sort(const float *boxes, const float *probs_in, float *probs, int ba
 int y2h_detect_chain_ok(const y2h_decode *q);
 int y2h_detect_chain(const y2h_decode *q, float nms, float *probs_nms, int *class_counts, float *records, int *counts,
                      int max_per_image, float *best_scratch /* 2 * batch * w*h*num floats, as y2h_collect, or 0 */, y2h_stream s);
+/* The same chain for a TREE head without a class map (yolo9000 in detect mode) in two launches.  region_layer.c:351-367
+ * leaves at most one non-zero score per box (the deepest class above .5, kept when the objectness exceeds q->thresh), so
+ * the dense [boxes][classes] arrays of y2h_region_boxes / y2h_nms_sort / y2h_collect (261 MB per batch of yolo9000 544 b8,
+ * walked six times) shrink to one (class, score) pair per box: same records and counts, no dense scores, and the prediction
+ * rows are NOT edited in place.  Needs the level-ordered tree (tree_order / tree_level_off), q->thresh >= 0, no
+ * only_objectness, <= 4096 boxes per image.  best_scratch: 2 * batch * w*h*num floats.  With `tree_best` (the region layer's
+ * own by-product for these predictions) the class rows are not read again at all: three small launches. */
+int y2h_detect_tree_chain_ok(const y2h_decode *q);
+int y2h_detect_tree_chain(const y2h_decode *q, float nms, float *records, int *counts, int max_per_image, float *best_scratch,
+                          const float *tree_best /* y2h_region_forward_tree_best's output for q->pred, or 0 */, y2h_stream s);
 /* class-agnostic variant, box.c:279-298 */
 int y2h_nms(const float *boxes, float *probs, int batch, int total, int classes, int stride,
             float thresh, y2h_stream s);

@@ -324,6 +324,12 @@ static int detect_enqueue(network net, float *d_pred, float thresh, float nms, i
         HIPCALL_I(y2h_detect_chain(&q, nms, e->d_probs_nms, e->d_class_counts, e->d_records, e->d_counts, e->det_cap, e->d_best, ds));
         goto fetch;
     }
+    if (y2h_detect_tree_chain_ok(&q)) {
+        /* tree head without a map (yolo9000): one (class, score) pair per box instead of the dense score arrays, two launches */
+        HIPCALL_I(y2h_detect_tree_chain(&q, nms, e->d_records, e->d_counts, e->det_cap, e->d_best,
+                                        (d_pred == d->d_region && d->tree_best_valid) ? d->d_tree_best : NULL, ds));
+        goto fetch;
+    }
     HIPCALL_I(y2h_region_boxes(&q, ds));
     }
     final_probs = e->d_probs;

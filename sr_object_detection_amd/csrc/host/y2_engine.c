@@ -156,7 +156,7 @@ void y2_engine_destroy(network *net)
         y2_ldev *d = ld_of(&net->layers[i]);
         if (!d) continue;
         y2h_free(d->d_anchors); y2h_free(d->d_tree_parent); y2h_free(d->d_tree_gsize); y2h_free(d->d_tree_goff); y2h_free(d->d_map);
-        y2h_free(d->d_tree_order); y2h_free(d->d_tree_loff);
+        y2h_free(d->d_tree_order); y2h_free(d->d_tree_loff); y2h_free(d->d_tree_best);
         free(d);
         net->layers[i].dev = NULL;
     }
@@ -882,6 +882,14 @@ int y2_engine_build(network *net)
                     }
                     d->tree_levels = maxd + 1;
                     free(loff);
+                    /* detect mode's (score, class) per box as a by-product of the region layer (y2h_region_forward_tree_best) */
+                    y2h_free(d->d_tree_best); d->d_tree_best = NULL;
+                    if (!l->map && l->coords == 4 && y2h_region_tree_best_ok(l->classes, d->tree_levels) &&
+                        y2h_malloc((void **)&d->d_tree_best, (size_t)2 * l->batch * l->h * l->w * l->n * sizeof(float))) {
+                        free(depth); free(order);
+                        y2_fail("tree scratch: %s", y2h_last_error());
+                        return -1;
+                    }
                 }
                 free(depth); free(order);
             }
@@ -1141,6 +1149,17 @@ static int enqueue_forward(network *net, const float *d_input_nchw)
             tree *t = l->softmax_tree;
             /* y2_set_detect_overlap: the previous batch's decode / NMS may still be reading d_region on det_stream */
             if (e->det_overlap && e->det_pending == 1 && i == e->out_layer && !e->capturing) HIPCALL(y2h_stream_wait_event(e->stream, e->ev_det));
+            /* The (score, class) pair per box that detect mode needs, as a by-product of this layer: it saves the detect call
+             * a sweep over the class rows (batch-1 latency), but it lengthens the forward; with y2_set_detect_overlap that
+             * sweep runs beside the NEXT forward on the detection stream, where it is the cheaper place (yolo9000 544 b8:
+             * 1999 against 1977 images/s, profiles/r03_notes.md section 10) */
+            d->tree_best_valid = 0;
+            if (t && d->d_tree_best && !e->det_overlap) d->tree_best_valid = 1;
+            if (d->tree_best_valid)
+                HIPCALL(y2h_region_forward_tree_best(x, ldx, d->d_region, l->batch, l->h * l->w, l->n, l->classes, l->coords, t->groups,
+                                                     d->d_tree_gsize, d->d_tree_goff, d->d_tree_parent, d->d_tree_order, d->d_tree_loff,
+                                                     d->tree_levels, d->d_tree_best, e->stream));
+            else
             HIPCALL(y2h_region_forward(x, ldx, d->d_region, l->batch, l->h * l->w, l->n, l->classes, l->coords, l->softmax,
                                        t ? t->groups : 0, d->d_tree_gsize, d->d_tree_goff, e->stream));
         } break;

@@ -34,6 +34,8 @@ typedef struct y2_ldev {
     int *d_tree_parent, *d_tree_gsize, *d_tree_goff, *d_map;
     int *d_tree_order, *d_tree_loff;   /* nodes by depth level (only when parents precede children) */
     int tree_levels;
+    float *d_tree_best;                /* [2 * boxes]: the region layer's (score | class) per box for y2h_detect_tree_chain, or NULL */
+    int tree_best_valid;               /* the last forward filled d_tree_best (it does unless the detection chain overlaps the next forward) */
     float *d_region;           /* [batch][outputs] flattened region output */
     /* classifier tail */
     float *d_flat;             /* avgpool / softmax output [batch][outputs] */

@@ -705,6 +705,263 @@ extern "C" int y2h_detect_chain(const y2h_decode *q, float nms, float *probs_nms
 }
 
 // ---------------------------------------------------------------------------
+// The detection chain of a TREE head without a class map (yolo9000 in detect mode: 9418 classes) in TWO launches.
+// region_layer.c:351-367 leaves at most ONE non-zero score per box -- the deepest class whose hierarchy probability
+// exceeds .5 (the last such index), kept only when the box's objectness exceeds the threshold -- so the dense
+// [boxes][classes] score array the reference hands to do_nms_sort / max_index (8 x 867 x 9418 floats = 261 MB per batch of
+// yolo9000 544, written by the decode, copied for the NMS, scanned by the class counts, by the NMS gather and by the
+// best-class search) is one (class, value) pair per box:
+//   decode_tree_sparse_kernel  one workgroup per box: the box (get_region_box), then -- only for boxes whose objectness
+//                              passes, the others cannot produce a score -- the class row staged in LDS, hierarchy products
+//                              level by level (as decode_tree_kernel: same fp32 multiplications), the last class above .5
+//   nms_collect_sparse_kernel  one workgroup per image: candidates sorted by (class, score descending, box index ascending)
+//                              -- do_nms_sort's order: with one non-zero class per box every tie of box.c:252-264's
+//                              repeated stable sort falls through to the box index --, greedy suppression inside each class
+//                              (one wavefront per class with two or more candidates), then max_index + the ordered
+//                              compaction of collect_kernel (a box whose score was suppressed has an all-zero row: best 0).
+// Same records and counts as y2h_region_boxes + y2h_nms_sort + y2h_collect (tests/test_gpu_ingest.py compares them); the
+// dense arrays and the in-place edit of the prediction rows (nobody reads them behind a detect call) are not produced.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_tree_sparse_kernel(DecodeK d, TreeK tk, float *__restrict__ cand_val, int *__restrict__ cand_cls)
+{
+    extern __shared__ __attribute__((aligned(16))) float row[];      // [classes]
+    __shared__ int s_best;
+    const long gi = blockIdx.x;
+    const int t = threadIdx.x;
+    const int size = d.classes + 5;
+    const float *x = d.pred + gi * size;
+    float scale = x[4];
+    if (d.classfix == -1 && scale < .5) scale = 0;
+    if (t == 0) {                                       // region_layer.c:73-85 get_region_box, as decode_boxes_kernel
+        const int total = d.w * d.h * d.num;
+        const int index = (int)(gi % total);
+        const int n = index % d.num, cell = index / d.num;
+        const int r = cell / d.w, col = cell % d.w;
+        float bx = (col + logistic_f(x[0])) / d.w;
+        float by = (r + logistic_f(x[1])) / d.h;
+        float bw = (float)(exp((double)x[2]) * d.anchors[2 * n] / d.w);
+        float bh = (float)(exp((double)x[3]) * d.anchors[2 * n + 1] / d.h);
+        bx *= d.img_w; by *= d.img_h; bw *= d.img_w; bh *= d.img_h;
+        float *bo = d.boxes + gi * 4;
+        bo[0] = bx; bo[1] = by; bo[2] = bw; bo[3] = bh;
+    }
+    if (!(scale > d.thresh)) {                          // uniform: every score of this box is zero (region_layer.c:364)
+        if (t == 0) { cand_val[gi] = 0.f; cand_cls[gi] = 0; }
+        return;
+    }
+    const float *p = x + 5;
+    for (int j = t; j < d.classes; j += 256) row[j] = p[j];
+    if (t == 0) s_best = -1;
+    __syncthreads();
+    for (int lv = 1; lv < tk.levels; ++lv) {            // tree.c:37-44, level by level (see decode_tree_kernel)
+        const int b = tk.level_off[lv], e = tk.level_off[lv + 1];
+        for (int i = b + t; i < e; i += 256) {
+            const int j = tk.order[i];
+            row[j] *= row[d.parent[j]];
+        }
+        __syncthreads();
+    }
+    int best = -1;
+    for (int j = t; j < d.classes; j += 256) if (row[j] > .5) best = j;       // ascending: keeps the last
+    if (best >= 0) atomicMax(&s_best, best);
+    __syncthreads();
+    if (t == 0) {
+        best = s_best;
+        cand_val[gi] = best >= 0 ? row[best] : 0.f;
+        cand_cls[gi] = best >= 0 ? best : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_collect_sparse_kernel(const float *__restrict__ boxes, const float *__restrict__ cand_val,
+                                                                 const int *__restrict__ cand_cls, int total, int cap, float nms,
+                                                                 float thresh, float *__restrict__ records, int *__restrict__ counts,
+                                                                 int max_per)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    unsigned long long *keys = (unsigned long long *)sp_smem;                   // [cap]  class << 48 | score bits << 16 | ~box index
+    float4 *s_box = (float4 *)(keys + cap);                                     // [cap]  boxes in sorted order
+    float *bval = (float *)(s_box + cap);                                       // [cap]  score per box (0: none / suppressed)
+    int *bcls = (int *)(bval + cap);                                            // [cap]
+    int *runs = bcls + cap;                                                     // [cap]  start << 16 | end of a class with >= 2 candidates
+    volatile unsigned char *dead = (volatile unsigned char *)(runs + cap);      // [cap]
+    __shared__ int s_count, s_runs, s_base;
+    __shared__ int s_scan[256];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float *bx = boxes + (size_t)b * total * 4;
+    if (t == 0) { s_count = 0; s_runs = 0; s_base = 0; }
+    __syncthreads();
+    for (int i = t; i < total; i += 256) {
+        const float v = cand_val[(size_t)b * total + i];
+        const int c = cand_cls[(size_t)b * total + i];
+        bval[i] = v; bcls[i] = c;
+        if (v != 0 && nms > 0) {
+            const int slot = atomicAdd(&s_count, 1);
+            keys[slot] = ((unsigned long long)(unsigned)c << 48) | ((unsigned long long)__float_as_uint(v) << 16) | (unsigned long long)((~(unsigned)i) & 0xffffu);
+        }
+    }
+    __syncthreads();
+    const int n = s_count;
+    if (n >= 2) {
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (int i = n + t; i < np2; i += 256) keys[i] = 0ull;
+        for (int i = t; i < np2; i += 256) dead[i] = 0;
+        __syncthreads();
+        for (int kk = 2; kk <= np2; kk <<= 1) {              // bitonic sort, descending
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int i = t; i < np2; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = keys[i], c = keys[ixj];
+                        const bool desc = ((i & kk) == 0);
+                        if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int j = t; j < n; j += 256) {
+            const unsigned idx = (~(unsigned)(keys[j] & 0xffffull)) & 0xffffu;
+            s_box[j] = *(const float4 *)(bx + (size_t)idx * 4);
+            const unsigned c = (unsigned)(keys[j] >> 48);
+            const bool starts = (j == 0 || (unsigned)(keys[j - 1] >> 48) != c) && (j + 1 < n && (unsigned)(keys[j + 1] >> 48) == c);
+            if (starts) {
+                int e = j + 1;
+                while (e < n && (unsigned)(keys[e] >> 48) == c) ++e;
+                runs[atomicAdd(&s_runs, 1)] = (j << 16) | e;
+            }
+        }
+        __syncthreads();
+        // greedy suppression (box.c:266-275), one wavefront per class: LDS operations of a wavefront execute in order, and
+        // `dead` is volatile, so a flag set by the inner loop is seen by the next round's test without a barrier
+        const int nr = s_runs;
+        for (int r = wv; r < nr; r += 4) {
+            const int rs = runs[r] >> 16, re = runs[r] & 0xffff;
+            for (int i = rs; i < re - 1; ++i) {
+                if (!dead[i]) {
+                    const float4 a = s_box[i];
+                    for (int j = i + 1 + lane; j < re; j += 64)
+                        if (box_iou_f(a, s_box[j]) > nms) dead[j] = 1;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int j = t; j < n; j += 256)
+            if (dead[j]) bval[(~(unsigned)(keys[j] & 0xffffull)) & 0xffffu] = 0.f;
+        __syncthreads();
+    }
+    // max_index over a row with at most one non-zero score, then collect_kernel's ordered compaction
+    float *rec = records + (size_t)b * max_per * 6;
+    for (int i0 = 0; i0 < total; i0 += 256) {
+        const int i = i0 + t;
+        float best = 0;
+        int cls = 0, keep = 0;
+        if (i < total) {
+            best = bval[i];
+            cls = best > 0 ? bcls[i] : 0;
+            keep = best > thresh;
+        }
+        s_scan[t] = keep;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = (t >= off) ? s_scan[t - off] : 0;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        const int pos = s_base + s_scan[t] - keep;
+        if (keep && pos < max_per) {
+            float *r = rec + (size_t)pos * 6;
+            r[0] = bx[(size_t)i * 4 + 0]; r[1] = bx[(size_t)i * 4 + 1];
+            r[2] = bx[(size_t)i * 4 + 2]; r[3] = bx[(size_t)i * 4 + 3];
+            r[4] = best; r[5] = (float)cls;
+        }
+        __syncthreads();
+        if (t == 255) s_base += s_scan[255];
+        __syncthreads();
+    }
+    if (t == 0) counts[b] = s_base;
+}
+
+// the first launch when the region layer has already produced the (score, class) pair of every box
+// (y2h_region_forward_tree_best): the box and the objectness test, one lane per box
+__global__ __launch_bounds__(256) void decode_tree_cand_kernel(DecodeK d, const float *__restrict__ pre_val, const int *__restrict__ pre_cls,
+                                                               float *__restrict__ cand_val, int *__restrict__ cand_cls)
+{
+    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= d.nboxes) return;
+    const int size = d.classes + 5;
+    const float *x = d.pred + gi * size;
+    float scale = x[4];
+    if (d.classfix == -1 && scale < .5) scale = 0;
+    const int total = d.w * d.h * d.num;
+    const int index = (int)(gi % total);
+    const int n = index % d.num, cell = index / d.num;
+    const int r = cell / d.w, col = cell % d.w;
+    float bx = (col + logistic_f(x[0])) / d.w;
+    float by = (r + logistic_f(x[1])) / d.h;
+    float bw = (float)(exp((double)x[2]) * d.anchors[2 * n] / d.w);
+    float bh = (float)(exp((double)x[3]) * d.anchors[2 * n + 1] / d.h);
+    bx *= d.img_w; by *= d.img_h; bw *= d.img_w; bh *= d.img_h;
+    float *bo = d.boxes + gi * 4;
+    bo[0] = bx; bo[1] = by; bo[2] = bw; bo[3] = bh;
+    const bool on = scale > d.thresh;
+    cand_val[gi] = on ? pre_val[gi] : 0.f;
+    cand_cls[gi] = on ? pre_cls[gi] : 0;
+}
+
+extern "C" int y2h_detect_tree_chain_ok(const y2h_decode *q)
+{
+    return q && q->tree_parent && !q->map && !q->only_objectness && q->thresh >= 0 && q->tree_order && q->tree_level_off &&
+           q->tree_levels > 0 && q->classes < 65536 && (size_t)q->classes * sizeof(float) <= 150 * 1024 &&
+           (long)q->w * q->h * q->num <= 4096 && !getenv("Y2_DETECT_SEPARATE");
+}
+
+// decode + NMS (nms > 0) + compaction of a tree head without a map; best_scratch: 2 * boxes floats (as y2h_collect)
+extern "C" int y2h_detect_tree_chain(const y2h_decode *q, float nms, float *records, int *counts, int max_per_image,
+                                     float *best_scratch, const float *tree_best, y2h_stream s)
+{
+    if (!y2h_detect_tree_chain_ok(q) || !q->pred || !q->boxes || !q->anchors || !records || !counts || !best_scratch || max_per_image <= 0 ||
+        q->batch <= 0 || q->w <= 0 || q->h <= 0 || q->num <= 0 || q->classes <= 0)
+        return Y2H_EINVAL;
+    DecodeK d;
+    d.w = q->w; d.h = q->h; d.num = q->num; d.classes = q->classes; d.img_w = q->img_w; d.img_h = q->img_h;
+    d.thresh = q->thresh; d.only_objectness = 0; d.classfix = q->classfix;
+    d.anchors = q->anchors; d.parent = q->tree_parent; d.map = nullptr;
+    d.pred = q->pred; d.boxes = q->boxes; d.probs = nullptr;
+    d.nboxes = (long)q->batch * q->w * q->h * q->num;
+    d.tree_seq = 0;
+    TreeK tk;
+    tk.order = q->tree_order; tk.level_off = q->tree_level_off; tk.levels = q->tree_levels;
+    const int total = q->w * q->h * q->num;
+    float *cand_val = best_scratch;
+    int *cand_cls = (int *)(best_scratch + d.nboxes);
+    int cap = 16;
+    while (cap < total) cap <<= 1;
+    const size_t lds2 = (size_t)cap * (8 + 16 + 4 + 4 + 4 + 1);
+    static bool attr_set[16] = {false};
+    int dev = 0;
+    Y2H_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        Y2H_CHECK(hipFuncSetAttribute((const void *)decode_tree_sparse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        Y2H_CHECK(hipFuncSetAttribute((const void *)nms_collect_sparse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 37));
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    if (tree_best)
+        hipLaunchKernelGGL(decode_tree_cand_kernel, dim3((unsigned)((d.nboxes + 255) / 256)), dim3(256), 0, S(s), d, tree_best,
+                           (const int *)(tree_best + d.nboxes), cand_val, cand_cls);
+    else
+        hipLaunchKernelGGL(decode_tree_sparse_kernel, dim3((unsigned)d.nboxes), dim3(256), (size_t)q->classes * sizeof(float), S(s), d, tk,
+                           cand_val, cand_cls);
+    Y2H_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_collect_sparse_kernel, dim3((unsigned)q->batch), dim3(256), lds2, S(s), q->boxes, cand_val, cand_cls, total, cap,
+                       nms, q->thresh, records, counts, max_per_image);
+    Y2H_LAUNCH_CHECK();
+    return Y2H_OK;
+}
+
+// ---------------------------------------------------------------------------
 // resize_image (image.c:1950-1992): separable align-corners bilinear, two fp32
 // passes (columns first into `tmp` [c][ih][w], then rows), same rounding order
 // ---------------------------------------------------------------------------

@@ -340,11 +340,26 @@ __global__ __launch_bounds__(256) void region_lds_kernel(const float *__restrict
 // loads, every thread then walks whole groups sequentially (the reference's order inside a group, softmax_seq),
 // and the result leaves coalesced.  The thread-per-(box,group) kernel above reads and writes 4-byte pieces
 // scattered over a 37 KB row (yolo9000: 590 us per 8 frames); this one moves each row once.
+//
+// With `tb.best_val` set the workgroup goes on, the row still in LDS, to what get_region_boxes will ask of it in detect mode
+// (region_layer.c:351-367 without a map): hierarchy_predictions (tree.c:37-44: every node times its parent's final value,
+// level by level -- nodes of one depth are independent when parents precede their children) and the deepest class whose
+// probability exceeds .5 (the LAST such index), as one (score, class) pair per box for y2h_detect_tree_chain.  None of it
+// depends on the detection threshold, and the layer's output is written before: the extra pass changes no output value
+// and saves the detect call a second sweep over the [boxes][classes] scores (261 MB per batch of yolo9000 544 b8).
+struct TreeBestK {
+    const int *parent, *order, *level_off;
+    int levels;
+    float *best_val;
+    int *best_cls;
+};
+
 __global__ __launch_bounds__(256) void region_tree_lds_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
                                                               int num, int classes, int coords, int groups,
-                                                              const int *__restrict__ gsize, const int *__restrict__ goff)
+                                                              const int *__restrict__ gsize, const int *__restrict__ goff, TreeBestK tb)
 {
     extern __shared__ float cls[];
+    __shared__ int s_best;
     const long i = blockIdx.x;                      // box
     const int size = coords + 1 + classes;
     const int a = (int)(i % num);
@@ -356,10 +371,40 @@ __global__ __launch_bounds__(256) void region_tree_lds_kernel(const float *__res
     for (int g = threadIdx.x; g < groups; g += 256) softmax_seq(cls + goff[g], gsize[g], 1.f, cls + goff[g]);
     __syncthreads();
     for (int k = threadIdx.x; k < classes; k += 256) dst[k] = cls[k];
+    if (!tb.best_val) return;
+    if (threadIdx.x == 0) s_best = -1;
+    __syncthreads();                                // every lane has read the row it stores before the row is edited
+    for (int lv = 1; lv < tb.levels; ++lv) {        // level 0 = roots (parent < 0): unchanged
+        const int b = tb.level_off[lv], e = tb.level_off[lv + 1];
+        for (int q = b + threadIdx.x; q < e; q += 256) {
+            const int j = tb.order[q];
+            cls[j] *= cls[tb.parent[j]];
+        }
+        __syncthreads();
+    }
+    int best = -1;
+    for (int j = threadIdx.x; j < classes; j += 256) if (cls[j] > .5) best = j;       // ascending: keeps the last
+    if (best >= 0) atomicMax(&s_best, best);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = s_best;
+        tb.best_val[i] = best >= 0 ? cls[best] : 0.f;
+        tb.best_cls[i] = best >= 0 ? best : 0;
+    }
 }
 
-extern "C" int y2h_region_forward(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
-                                  int softmax, int groups, const int *group_size, const int *group_offset, y2h_stream s)
+static bool region_tree_lds_ok(int classes, long boxes)
+{
+    return (size_t)classes * sizeof(float) <= 64 * 1024 && boxes < 0x7fffffffL && !getenv("Y2_REGION_TREE_SIMPLE");
+}
+
+extern "C" int y2h_region_tree_best_ok(int classes, int levels)
+{
+    return levels > 0 && region_tree_lds_ok(classes, 1) && !getenv("Y2_NO_TREE_BEST");
+}
+
+static int region_forward_impl(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
+                               int softmax, int groups, const int *group_size, const int *group_offset, TreeBestK tb, y2h_stream s)
 {
     if (batch <= 0 || hw <= 0 || num <= 0 || classes <= 0 || coords != 4) return Y2H_EINVAL;
     if (ldx < num * (coords + 1 + classes)) return Y2H_EINVAL;
@@ -375,15 +420,35 @@ extern "C" int y2h_region_forward(const float *x, int ldx, float *y, int batch, 
     Y2H_LAUNCH_CHECK();
     if (groups > 0) {
         if (!group_size || !group_offset) return Y2H_EINVAL;
-        if ((size_t)classes * sizeof(float) <= 64 * 1024 && boxes < 0x7fffffffL && !getenv("Y2_REGION_TREE_SIMPLE"))
+        if (region_tree_lds_ok(classes, boxes))
             hipLaunchKernelGGL(region_tree_lds_kernel, dim3((unsigned)boxes), dim3(256), (size_t)classes * sizeof(float), S(s),
-                               x, ldx, y, num, classes, coords, groups, group_size, group_offset);
-        else
+                               x, ldx, y, num, classes, coords, groups, group_size, group_offset, tb);
+        else {
+            if (tb.best_val) return Y2H_EINVAL;          // (y2h_region_tree_best_ok said no)
             hipLaunchKernelGGL(region_tree_kernel, dim3(y2h_grid(boxes * groups, 256, 256 * 64)), dim3(256), 0, S(s),
                                x, ldx, y, boxes, num, classes, coords, groups, group_size, group_offset);
+        }
         Y2H_LAUNCH_CHECK();
-    }
+    } else if (tb.best_val) return Y2H_EINVAL;
     return Y2H_OK;
+}
+
+extern "C" int y2h_region_forward(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
+                                  int softmax, int groups, const int *group_size, const int *group_offset, y2h_stream s)
+{
+    TreeBestK tb = {nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    return region_forward_impl(x, ldx, y, batch, hw, num, classes, coords, softmax, groups, group_size, group_offset, tb, s);
+}
+
+extern "C" int y2h_region_forward_tree_best(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
+                                            int groups, const int *group_size, const int *group_offset, const int *parent,
+                                            const int *order, const int *level_off, int levels, float *best /* val[boxes] | cls[boxes] */,
+                                            y2h_stream s)
+{
+    if (!parent || !order || !level_off || !best || groups <= 0 || !y2h_region_tree_best_ok(classes, levels)) return Y2H_EINVAL;
+    const long boxes = (long)batch * hw * num;
+    TreeBestK tb = {parent, order, level_off, levels, best, (int *)(best + boxes)};
+    return region_forward_impl(x, ldx, y, batch, hw, num, classes, coords, 1, groups, group_size, group_offset, tb, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -155,6 +155,60 @@ def test_yolo9000_544_batch8_matches_reference(workdir):
     net.free()
 
 
+def test_yolo9000_sparse_detect_chain_matches_reference_and_dense_path(workdir, monkeypatch):
+    """detect mode of a tree head (yolo9000 544, four frames): y2h_detect_tree_chain -- one (class, score) pair per box, two
+    launches -- against (1) the dense path it replaces (Y2_DETECT_SEPARATE=1: y2h_region_boxes + y2h_nms_sort + y2h_collect
+    over the [867][9418] score arrays), records and counts identical at four (thresh, nms) settings, and (2) the REFERENCE's
+    post-NMS scores of the golden (region_layer.c:328-379 with the hierarchy, tree.c:37, box.c:249-277): the same boxes
+    keep the same class, scores within 1e-4, in ascending box order (yolo_v2_class.cpp:221-238)"""
+    g = load_golden("yolo9000_544_b2")
+    batch, size, thresh, nms = 4, int(g["size"]), float(g["thresh"]), float(g["nms"])
+    cfg, wts, _ = materialize(workdir, "yolo9000", size, batch, int(g["seed"]), float(g["head_gain"]))
+    x, which = _batch_from_golden(g, batch)
+    settings = ((thresh, nms), (0.05, 0.4), (thresh, 0.0), (0.6, 0.2))
+    results = {}
+    # separate: the dense path; sparse: the pair per box comes out of the region layer itself (y2h_region_forward_tree_best);
+    # sparse-sweep: from decode_tree_sparse_kernel's own sweep over the class rows (what runs beside the next forward
+    # under y2_set_detect_overlap, and for predictions the caller hands in)
+    for mode in ("separate", "sparse", "sparse-sweep"):
+        if mode == "separate":
+            monkeypatch.setenv("Y2_DETECT_SEPARATE", "1")
+        else:
+            monkeypatch.delenv("Y2_DETECT_SEPARATE", raising=False)
+        if mode == "sparse-sweep":
+            monkeypatch.setenv("Y2_NO_TREE_BEST", "1")
+        else:
+            monkeypatch.delenv("Y2_NO_TREE_BEST", raising=False)
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        l = net.last
+        total, classes = l.w * l.h * l.n, l.classes
+        got = []
+        for th, nm in settings:
+            net.network_predict(x)            # the dense path edits the prediction rows in place: a fresh forward per call
+            got.append(net.detect_resident(th, nm))
+        results[mode] = got
+        net.free()
+    kept = []
+    for other in ("sparse", "sparse-sweep"):
+        for (da, ca), (db, cb) in zip(results["separate"], results[other]):
+            assert np.array_equal(ca, cb), other
+            kept.append(int(ca.sum()))
+            for a, b in zip(da, db):
+                assert np.array_equal(a, b), other
+    assert kept[0] > 0 and kept[2] >= kept[0], kept        # something is detected; without NMS at least as much
+    dets, counts = results["sparse"][0]
+    for b in range(batch):
+        k = which[b]
+        gpost = dense_from_sparse(g["post_idx_%d" % k], g["post_val_%d" % k], total, classes)
+        rows = np.flatnonzero(gpost.max(axis=1) > thresh)
+        assert int(counts[b]) == len(rows), "batch item %d" % b
+        d = dets[b]
+        assert np.array_equal(d["obj_id"], gpost[rows].argmax(axis=1))
+        assert np.abs(d["prob"] - gpost[rows].max(axis=1)).max() < TOL
+        assert boxes_close(np.stack([d["x"], d["y"], d["w"], d["h"]], 1), g["boxes_%d" % k][rows])
+
+
 def test_darknet19_448_fp32_batch32_matches_reference(workdir, oracle):
     g = load_golden("darknet19_448_b8")
     batch = 32
