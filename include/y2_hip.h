@@ -266,15 +266,20 @@ int y2h_f16_to_f32(const void *src, float *dst, long n, y2h_stream s);
  * (group_size/group_offset device arrays, groups>0) on the class scores. */
 int y2h_region_forward(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
                        int softmax, int groups, const int *group_size, const int *group_offset, y2h_stream s);
-/* The same for a tree head, plus -- from the class row still in LDS -- what get_region_boxes needs of it in detect mode
- * (region_layer.c:351-367 without a map; tree.c:37-44): best[0 .. boxes) = hierarchy probability of the deepest class above
- * .5 (0: none), best[boxes .. 2 boxes) = that class as int.  Independent of the detection threshold; y is written exactly
- * as by y2h_region_forward.  parent / order / level_off / levels: the tree with its nodes listed by depth level (parents
- * precede children).  y2h_region_tree_best_ok: 1 when the row fits the LDS kernel. */
+/* The same for a tree head (groups > 0), with two options.
+ * best != 0: from the class row still in LDS, what get_region_boxes needs of it in detect mode (region_layer.c:351-367
+ *   without a map; tree.c:37-44): best[0 .. boxes) = hierarchy probability of the deepest class above .5 (0: none),
+ *   best[boxes .. 2 boxes) = that class as int.  Independent of the detection threshold; y is written exactly as without.
+ *   parent / order / level_off / levels: the tree with its nodes listed by depth level (parents precede children);
+ *   y2h_region_tree_best_ok: 1 when the row fits the LDS kernel.
+ * flags & Y2H_REGION_FAST_EXP: the group softmax takes expf (single precision, ~1 ulp) where the reference rounds a double
+ *   exp to float (blas.c softmax): outputs differ by ~1e-7 relative, sums run in the reference's order.  The double exps are
+ *   what the layer costs (9418 per box in yolo9000).  Env Y2_REGION_EXP_DOUBLE=1 overrides the flag. */
+#define Y2H_REGION_FAST_EXP 1
 int y2h_region_tree_best_ok(int classes, int levels);
-int y2h_region_forward_tree_best(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
-                                 int groups, const int *group_size, const int *group_offset, const int *parent,
-                                 const int *order, const int *level_off, int levels, float *best, y2h_stream s);
+int y2h_region_forward_tree(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
+                            int groups, const int *group_size, const int *group_offset, const int *parent,
+                            const int *order, const int *level_off, int levels, float *best, int flags, y2h_stream s);
 
 typedef struct y2h_decode {
     int batch, w, h, num, classes;
@@ -325,7 +330,7 @@ int y2h_detect_chain(const y2h_decode *q, float nms, float *probs_nms, int *clas
  * own by-product for these predictions) the class rows are not read again at all: three small launches. */
 int y2h_detect_tree_chain_ok(const y2h_decode *q);
 int y2h_detect_tree_chain(const y2h_decode *q, float nms, float *records, int *counts, int max_per_image, float *best_scratch,
-                          const float *tree_best /* y2h_region_forward_tree_best's output for q->pred, or 0 */, y2h_stream s);
+                          const float *tree_best /* y2h_region_forward_tree's `best` for q->pred, or 0 */, y2h_stream s);
 /* class-agnostic variant, box.c:279-298 */
 int y2h_nms(const float *boxes, float *probs, int batch, int total, int classes, int stride,
             float thresh, y2h_stream s);

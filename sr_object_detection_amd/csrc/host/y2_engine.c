@@ -882,7 +882,7 @@ int y2_engine_build(network *net)
                     }
                     d->tree_levels = maxd + 1;
                     free(loff);
-                    /* detect mode's (score, class) per box as a by-product of the region layer (y2h_region_forward_tree_best) */
+                    /* detect mode's (score, class) per box as a by-product of the region layer (y2h_region_forward_tree) */
                     y2h_free(d->d_tree_best); d->d_tree_best = NULL;
                     if (!l->map && l->coords == 4 && y2h_region_tree_best_ok(l->classes, d->tree_levels) &&
                         y2h_malloc((void **)&d->d_tree_best, (size_t)2 * l->batch * l->h * l->w * l->n * sizeof(float))) {
@@ -1155,13 +1155,16 @@ static int enqueue_forward(network *net, const float *d_input_nchw)
              * 1999 against 1977 images/s, profiles/r03_notes.md section 10) */
             d->tree_best_valid = 0;
             if (t && d->d_tree_best && !e->det_overlap) d->tree_best_valid = 1;
-            if (d->tree_best_valid)
-                HIPCALL(y2h_region_forward_tree_best(x, ldx, d->d_region, l->batch, l->h * l->w, l->n, l->classes, l->coords, t->groups,
-                                                     d->d_tree_gsize, d->d_tree_goff, d->d_tree_parent, d->d_tree_order, d->d_tree_loff,
-                                                     d->tree_levels, d->d_tree_best, e->stream));
+            if (t)
+                /* (strict mode keeps the reference's double exp in the group softmax; otherwise expf: the 9418 double exps per
+                 * box are what this layer costs in yolo9000) */
+                HIPCALL(y2h_region_forward_tree(x, ldx, d->d_region, l->batch, l->h * l->w, l->n, l->classes, l->coords, t->groups,
+                                                d->d_tree_gsize, d->d_tree_goff, d->d_tree_parent, d->d_tree_order, d->d_tree_loff,
+                                                d->tree_levels, d->tree_best_valid ? d->d_tree_best : NULL,
+                                                e->strict ? 0 : Y2H_REGION_FAST_EXP, e->stream));
             else
             HIPCALL(y2h_region_forward(x, ldx, d->d_region, l->batch, l->h * l->w, l->n, l->classes, l->coords, l->softmax,
-                                       t ? t->groups : 0, d->d_tree_gsize, d->d_tree_goff, e->stream));
+                                       0, d->d_tree_gsize, d->d_tree_goff, e->stream));
         } break;
         case AVGPOOL:
             if (i > 0 && ld_of(&net->layers[i - 1])->out_half)

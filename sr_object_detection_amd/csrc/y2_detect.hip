@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256) void nms_collect_sparse_kernel(const float *__
 }
 
 // the first launch when the region layer has already produced the (score, class) pair of every box
-// (y2h_region_forward_tree_best): the box and the objectness test, one lane per box
+// (y2h_region_forward_tree): the box and the objectness test, one lane per box
 __global__ __launch_bounds__(256) void decode_tree_cand_kernel(DecodeK d, const float *__restrict__ pre_val, const int *__restrict__ pre_cls,
                                                                float *__restrict__ cand_val, int *__restrict__ cand_cls)
 {

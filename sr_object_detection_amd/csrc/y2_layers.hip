@@ -192,6 +192,21 @@ __device__ __forceinline__ void softmax_seq(const float *in, int n, float temp, 
     for (int i = 0; i < n; ++i) out[i] /= sum;
 }
 
+// The same walk with the single-precision exponential (expf, ~1 ulp) in place of the reference's double exp rounded to float
+// (blas.c:softmax): results differ by ~1e-7 relative, the order of the sums is the reference's.  9418 double exps per box are
+// what region_tree_lds_kernel spends its time on (yolo9000 544 b8: 223 us per batch on the forward's critical path).
+__device__ __forceinline__ void softmax_seq_fast(const float *in, int n, float temp, float *out)
+{
+    float sum = 0.f, largest = -FLT_MAX;
+    for (int i = 0; i < n; ++i) if (in[i] > largest) largest = in[i];
+    for (int i = 0; i < n; ++i) {
+        const float e = expf(in[i] / temp - largest / temp);
+        sum += e;
+        out[i] = e;
+    }
+    for (int i = 0; i < n; ++i) out[i] /= sum;
+}
+
 // One workgroup per row.  The maximum (order-independent) and the double-precision exp of every
 // element (the expensive part) are done by all lanes; only the fp32 running sum -- whose order the
 // reference fixes -- is walked by one lane, so the result is still bit-identical to softmax_seq.
@@ -354,6 +369,7 @@ struct TreeBestK {
     int *best_cls;
 };
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void region_tree_lds_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
                                                               int num, int classes, int coords, int groups,
                                                               const int *__restrict__ gsize, const int *__restrict__ goff, TreeBestK tb)
@@ -368,7 +384,10 @@ __global__ __launch_bounds__(256) void region_tree_lds_kernel(const float *__res
     float *dst = y + i * size + coords + 1;
     for (int k = threadIdx.x; k < classes; k += 256) cls[k] = src[k];
     __syncthreads();
-    for (int g = threadIdx.x; g < groups; g += 256) softmax_seq(cls + goff[g], gsize[g], 1.f, cls + goff[g]);
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        if (FAST) softmax_seq_fast(cls + goff[g], gsize[g], 1.f, cls + goff[g]);
+        else softmax_seq(cls + goff[g], gsize[g], 1.f, cls + goff[g]);
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < classes; k += 256) dst[k] = cls[k];
     if (!tb.best_val) return;
@@ -404,7 +423,7 @@ extern "C" int y2h_region_tree_best_ok(int classes, int levels)
 }
 
 static int region_forward_impl(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
-                               int softmax, int groups, const int *group_size, const int *group_offset, TreeBestK tb, y2h_stream s)
+                               int softmax, int groups, const int *group_size, const int *group_offset, TreeBestK tb, int flags, y2h_stream s)
 {
     if (batch <= 0 || hw <= 0 || num <= 0 || classes <= 0 || coords != 4) return Y2H_EINVAL;
     if (ldx < num * (coords + 1 + classes)) return Y2H_EINVAL;
@@ -420,10 +439,14 @@ static int region_forward_impl(const float *x, int ldx, float *y, int batch, int
     Y2H_LAUNCH_CHECK();
     if (groups > 0) {
         if (!group_size || !group_offset) return Y2H_EINVAL;
-        if (region_tree_lds_ok(classes, boxes))
-            hipLaunchKernelGGL(region_tree_lds_kernel, dim3((unsigned)boxes), dim3(256), (size_t)classes * sizeof(float), S(s),
-                               x, ldx, y, num, classes, coords, groups, group_size, group_offset, tb);
-        else {
+        if (region_tree_lds_ok(classes, boxes)) {
+            if ((flags & Y2H_REGION_FAST_EXP) && !getenv("Y2_REGION_EXP_DOUBLE"))
+                hipLaunchKernelGGL(region_tree_lds_kernel<true>, dim3((unsigned)boxes), dim3(256), (size_t)classes * sizeof(float), S(s),
+                                   x, ldx, y, num, classes, coords, groups, group_size, group_offset, tb);
+            else
+                hipLaunchKernelGGL(region_tree_lds_kernel<false>, dim3((unsigned)boxes), dim3(256), (size_t)classes * sizeof(float), S(s),
+                                   x, ldx, y, num, classes, coords, groups, group_size, group_offset, tb);
+        } else {
             if (tb.best_val) return Y2H_EINVAL;          // (y2h_region_tree_best_ok said no)
             hipLaunchKernelGGL(region_tree_kernel, dim3(y2h_grid(boxes * groups, 256, 256 * 64)), dim3(256), 0, S(s),
                                x, ldx, y, boxes, num, classes, coords, groups, group_size, group_offset);
@@ -437,18 +460,19 @@ extern "C" int y2h_region_forward(const float *x, int ldx, float *y, int batch, 
                                   int softmax, int groups, const int *group_size, const int *group_offset, y2h_stream s)
 {
     TreeBestK tb = {nullptr, nullptr, nullptr, 0, nullptr, nullptr};
-    return region_forward_impl(x, ldx, y, batch, hw, num, classes, coords, softmax, groups, group_size, group_offset, tb, s);
+    return region_forward_impl(x, ldx, y, batch, hw, num, classes, coords, softmax, groups, group_size, group_offset, tb, 0, s);
 }
 
-extern "C" int y2h_region_forward_tree_best(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
-                                            int groups, const int *group_size, const int *group_offset, const int *parent,
-                                            const int *order, const int *level_off, int levels, float *best /* val[boxes] | cls[boxes] */,
-                                            y2h_stream s)
+extern "C" int y2h_region_forward_tree(const float *x, int ldx, float *y, int batch, int hw, int num, int classes, int coords,
+                                       int groups, const int *group_size, const int *group_offset, const int *parent,
+                                       const int *order, const int *level_off, int levels, float *best /* val[boxes] | cls[boxes], or 0 */,
+                                       int flags, y2h_stream s)
 {
-    if (!parent || !order || !level_off || !best || groups <= 0 || !y2h_region_tree_best_ok(classes, levels)) return Y2H_EINVAL;
+    if (groups <= 0) return Y2H_EINVAL;
+    if (best && (!parent || !order || !level_off || !y2h_region_tree_best_ok(classes, levels))) return Y2H_EINVAL;
     const long boxes = (long)batch * hw * num;
-    TreeBestK tb = {parent, order, level_off, levels, best, (int *)(best + boxes)};
-    return region_forward_impl(x, ldx, y, batch, hw, num, classes, coords, 1, groups, group_size, group_offset, tb, s);
+    TreeBestK tb = {parent, order, level_off, levels, best, best ? (int *)(best + boxes) : nullptr};
+    return region_forward_impl(x, ldx, y, batch, hw, num, classes, coords, 1, groups, group_size, group_offset, tb, flags, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -167,7 +167,7 @@ def test_yolo9000_sparse_detect_chain_matches_reference_and_dense_path(workdir, 
     x, which = _batch_from_golden(g, batch)
     settings = ((thresh, nms), (0.05, 0.4), (thresh, 0.0), (0.6, 0.2))
     results = {}
-    # separate: the dense path; sparse: the pair per box comes out of the region layer itself (y2h_region_forward_tree_best);
+    # separate: the dense path; sparse: the pair per box comes out of the region layer itself (y2h_region_forward_tree);
     # sparse-sweep: from decode_tree_sparse_kernel's own sweep over the class rows (what runs beside the next forward
     # under y2_set_detect_overlap, and for predictions the caller hands in)
     for mode in ("separate", "sparse", "sparse-sweep"):
