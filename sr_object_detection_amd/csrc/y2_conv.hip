@@ -1763,9 +1763,10 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         a.xbytes = (unsigned)((size_t)d->batch * 3 * d->h * d->w * 4);
         const long ntiles = ((long)a.npix + 31) / 32;
         long blocks = (ntiles + 3) / 4;
-        if (blocks > 256 * 4) blocks = 256 * 4;
-        if (d->n <= 32) hipLaunchKernelGGL(conv_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
-        else hipLaunchKernelGGL(conv_first_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+        void (*fn)(ConvK) = d->n <= 32 ? conv_first_kernel<1> : conv_first_kernel<2>;
+        const long res = resident_blocks((const void *)fn, 256, 0, 3);
+        if (blocks > res) blocks = res;              // tiles are grid-strided
+        hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
         Y2H_LAUNCH_CHECK();
         return Y2H_OK;
     }
@@ -1783,9 +1784,10 @@ extern "C" int y2h_conv_forward(const y2h_conv *d, int strict, y2h_stream s)
         a.xbytes = (unsigned)((size_t)d->batch * (d->h + 2) * (d->w + 2) * d->ldx * 4);
         const long ntiles = ((long)a.npix + 31) / 32;
         long blocks = (ntiles + 3) / 4;
-        if (blocks > 256 * 4) blocks = 256 * 4;      // 4 waves per SIMD, tiles are grid-strided
-        if (d->n <= 32) hipLaunchKernelGGL(conv_first_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
-        else hipLaunchKernelGGL(conv_first_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+        void (*fn)(ConvK) = d->n <= 32 ? conv_first_kernel<1> : conv_first_kernel<2>;
+        const long res = resident_blocks((const void *)fn, 256, 0, 3);
+        if (blocks > res) blocks = res;              // tiles are grid-strided
+        hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
         Y2H_LAUNCH_CHECK();
         return Y2H_OK;
     }

@@ -2076,9 +2076,10 @@ int y2_f16_first_launch(const y2h_conv *d, ConvK &a, y2h_stream s)
     const long ntiles = ((long)a.npix + 31) / 32;
     a.vec_store = d->y_f16 && d->ldy % 8 == 0 && d->n % 8 == 0 && ((uintptr_t)d->y % 16) == 0 && !getenv("Y2_C32_SCALAR");
     long blocks = (ntiles + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;          // tiles are grid-strided
-    if (d->n <= 32) hipLaunchKernelGGL(conv_first_f16_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
-    else hipLaunchKernelGGL(conv_first_f16_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
+    void (*fn)(ConvK) = d->n <= 32 ? conv_first_f16_kernel<1> : conv_first_f16_kernel<2>;
+    const long res = resident_blocks((const void *)fn, 256, 0, 3);
+    if (blocks > res) blocks = res;                  // tiles are grid-strided
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, S(s), a);
     Y2H_LAUNCH_CHECK();
     return Y2H_OK;
 }

@@ -133,3 +133,23 @@ bool y2_f16_first_ok(const y2h_conv *d);
 int y2_f16_first_launch(const y2h_conv *d, ConvK &a, y2h_stream s);
 bool y2_f16_first_nchw_ok(const y2h_conv *d);
 int y2_f16_first_nchw_launch(const y2h_conv *d, ConvK &a, y2h_stream s);
+
+// Grid of a kernel that walks its tiles with a grid stride: exactly what is co-resident (256 CUs x the runtime's answer for
+// this kernel), no more -- a surplus block only starts when a resident one has finished ALL its tiles, i.e. runs a second,
+// nearly empty round (the first-layer kernel asked for four blocks per CU with registers for three: 1024 blocks, 768
+// resident).  Cached per kernel and device.
+static inline long resident_blocks(const void *fn, int threads, size_t lds, long fallback_per_cu)
+{
+    struct Entry { const void *fn; int dev; size_t lds; int per_cu; };
+    static Entry cache[32];
+    static int n = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256L * fallback_per_cu;
+    for (int i = 0; i < n; ++i) if (cache[i].fn == fn && cache[i].dev == dev && cache[i].lds == lds) return 256L * cache[i].per_cu;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = (int)fallback_per_cu;
+    if (getenv("Y2_FIRST_GRID_PER_CU")) per_cu = atoi(getenv("Y2_FIRST_GRID_PER_CU")) > 0 ? atoi(getenv("Y2_FIRST_GRID_PER_CU")) : per_cu;
+    if (n < 32) { cache[n].fn = fn; cache[n].dev = dev; cache[n].lds = lds; cache[n].per_cu = per_cu; ++n; }
+    return 256L * per_cu;
+}
+
