@@ -209,6 +209,42 @@ def test_yolo9000_sparse_detect_chain_matches_reference_and_dense_path(workdir, 
         assert boxes_close(np.stack([d["x"], d["y"], d["w"], d["h"]], 1), g["boxes_%d" % k][rows])
 
 
+@pytest.mark.parametrize("no_tree_best", [False, True], ids=["region-byproduct", "own-sweep"])
+def test_yolo9000_sparse_detect_chain_edge_cases(workdir, monkeypatch, no_tree_best):
+    """the one-pair-per-box chain of tree heads at its edges, against the dense chain (Y2_DETECT_SEPARATE=1) on a 288x288
+    yolo9000 (243 boxes per image, three images): a threshold nothing passes (zero records, zero counts), a record block
+    smaller than the number of detections (counts keep counting, the block holds the first max_per_image in box order:
+    yolo_v2_class.cpp:221-238's loop order), no NMS, and an NMS threshold of zero (every overlapping pair of a class suppresses)"""
+    cfg, wts, _ = materialize(workdir, "yolo9000", 288, 3, 77, 6.0)
+    x = synth.image_batch(3, 3, 288, 288, seed=4321)
+    results = {}
+    for mode in ("separate", "sparse"):
+        if mode == "separate":
+            monkeypatch.setenv("Y2_DETECT_SEPARATE", "1")
+        else:
+            monkeypatch.delenv("Y2_DETECT_SEPARATE", raising=False)
+        if no_tree_best:
+            monkeypatch.setenv("Y2_NO_TREE_BEST", "1")
+        else:
+            monkeypatch.delenv("Y2_NO_TREE_BEST", raising=False)
+        net = darknet.Network.parse_network_cfg(cfg)
+        net.load_weights(wts)
+        got = []
+        for th, nm, cap in ((0.999, 0.4, None), (0.01, 0.4, 7), (0.01, 0.0, None), (0.01, 1e-6, None), (0.3, 0.45, 1)):
+            net.network_predict(x)
+            got.append(net.detect_resident(th, nm, max_per_image=cap))
+        results[mode] = got
+        net.free()
+    for k, ((da, ca), (db, cb)) in enumerate(zip(results["separate"], results["sparse"])):
+        assert np.array_equal(ca, cb), k
+        for a, b in zip(da, db):
+            assert np.array_equal(a, b), k
+    assert int(results["sparse"][0][1].sum()) == 0
+    c1 = results["sparse"][1][1]
+    assert (c1 > 7).any() and all(len(d) <= 7 for d in results["sparse"][1][0])      # truncated blocks, full counts
+    assert int(results["sparse"][2][1].sum()) >= int(results["sparse"][3][1].sum()) > 0
+
+
 def test_darknet19_448_fp32_batch32_matches_reference(workdir, oracle):
     g = load_golden("darknet19_448_b8")
     batch = 32
