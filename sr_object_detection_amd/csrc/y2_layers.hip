@@ -369,8 +369,11 @@ struct TreeBestK {
     int *best_cls;
 };
 
+#ifndef RT_NT
+#define RT_NT 512        // threads per box: 8 wavefronts keep twice the bytes of a 37 KB row in flight (four rows per CU by LDS)
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(256) void region_tree_lds_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
+__global__ __launch_bounds__(RT_NT) void region_tree_lds_kernel(const float *__restrict__ x, int ldx, float *__restrict__ y,
                                                               int num, int classes, int coords, int groups,
                                                               const int *__restrict__ gsize, const int *__restrict__ goff, TreeBestK tb)
 {
@@ -382,27 +385,27 @@ __global__ __launch_bounds__(256) void region_tree_lds_kernel(const float *__res
     const long cell = i / num;
     const float *src = x + cell * ldx + (long)a * size + coords + 1;
     float *dst = y + i * size + coords + 1;
-    for (int k = threadIdx.x; k < classes; k += 256) cls[k] = src[k];
+    for (int k = threadIdx.x; k < classes; k += RT_NT) cls[k] = src[k];
     __syncthreads();
-    for (int g = threadIdx.x; g < groups; g += 256) {
+    for (int g = threadIdx.x; g < groups; g += RT_NT) {
         if (FAST) softmax_seq_fast(cls + goff[g], gsize[g], 1.f, cls + goff[g]);
         else softmax_seq(cls + goff[g], gsize[g], 1.f, cls + goff[g]);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < classes; k += 256) dst[k] = cls[k];
+    for (int k = threadIdx.x; k < classes; k += RT_NT) dst[k] = cls[k];
     if (!tb.best_val) return;
     if (threadIdx.x == 0) s_best = -1;
     __syncthreads();                                // every lane has read the row it stores before the row is edited
     for (int lv = 1; lv < tb.levels; ++lv) {        // level 0 = roots (parent < 0): unchanged
         const int b = tb.level_off[lv], e = tb.level_off[lv + 1];
-        for (int q = b + threadIdx.x; q < e; q += 256) {
+        for (int q = b + threadIdx.x; q < e; q += RT_NT) {
             const int j = tb.order[q];
             cls[j] *= cls[tb.parent[j]];
         }
         __syncthreads();
     }
     int best = -1;
-    for (int j = threadIdx.x; j < classes; j += 256) if (cls[j] > .5) best = j;       // ascending: keeps the last
+    for (int j = threadIdx.x; j < classes; j += RT_NT) if (cls[j] > .5) best = j;       // ascending: keeps the last
     if (best >= 0) atomicMax(&s_best, best);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -441,10 +444,10 @@ static int region_forward_impl(const float *x, int ldx, float *y, int batch, int
         if (!group_size || !group_offset) return Y2H_EINVAL;
         if (region_tree_lds_ok(classes, boxes)) {
             if ((flags & Y2H_REGION_FAST_EXP) && !getenv("Y2_REGION_EXP_DOUBLE"))
-                hipLaunchKernelGGL(region_tree_lds_kernel<true>, dim3((unsigned)boxes), dim3(256), (size_t)classes * sizeof(float), S(s),
+                hipLaunchKernelGGL(region_tree_lds_kernel<true>, dim3((unsigned)boxes), dim3(RT_NT), (size_t)classes * sizeof(float), S(s),
                                    x, ldx, y, num, classes, coords, groups, group_size, group_offset, tb);
             else
-                hipLaunchKernelGGL(region_tree_lds_kernel<false>, dim3((unsigned)boxes), dim3(256), (size_t)classes * sizeof(float), S(s),
+                hipLaunchKernelGGL(region_tree_lds_kernel<false>, dim3((unsigned)boxes), dim3(RT_NT), (size_t)classes * sizeof(float), S(s),
                                    x, ldx, y, num, classes, coords, groups, group_size, group_offset, tb);
         } else {
             if (tb.best_val) return Y2H_EINVAL;          // (y2h_region_tree_best_ok said no)
