@@ -751,19 +751,19 @@ __global__ __launch_bounds__(DTS_NT) void decode_tree_sparse_kernel(DecodeK d, T
         return;
     }
     const float *p = x + 5;
-    for (int j = t; j < d.classes; j += DTS_NT) row[j] = p[j];
+    for (int j = t; j < d.classes; j += (int)blockDim.x) row[j] = p[j];
     if (t == 0) s_best = -1;
     __syncthreads();
     for (int lv = 1; lv < tk.levels; ++lv) {            // tree.c:37-44, level by level (see decode_tree_kernel)
         const int b = tk.level_off[lv], e = tk.level_off[lv + 1];
-        for (int i = b + t; i < e; i += DTS_NT) {
+        for (int i = b + t; i < e; i += (int)blockDim.x) {
             const int j = tk.order[i];
             row[j] *= row[d.parent[j]];
         }
         __syncthreads();
     }
     int best = -1;
-    for (int j = t; j < d.classes; j += DTS_NT) if (row[j] > .5) best = j;       // ascending: keeps the last
+    for (int j = t; j < d.classes; j += (int)blockDim.x) if (row[j] > .5) best = j;       // ascending: keeps the last
     if (best >= 0) atomicMax(&s_best, best);
     __syncthreads();
     if (t == 0) {
@@ -953,7 +953,7 @@ extern "C" int y2h_detect_tree_chain(const y2h_decode *q, float nms, float *reco
         hipLaunchKernelGGL(decode_tree_cand_kernel, dim3((unsigned)((d.nboxes + 255) / 256)), dim3(256), 0, S(s), d, tree_best,
                            (const int *)(tree_best + d.nboxes), cand_val, cand_cls);
     else
-        hipLaunchKernelGGL(decode_tree_sparse_kernel, dim3((unsigned)d.nboxes), dim3(DTS_NT), (size_t)q->classes * sizeof(float), S(s), d, tk,
+        hipLaunchKernelGGL(decode_tree_sparse_kernel, dim3((unsigned)d.nboxes), dim3(getenv("Y2_DTS_THREADS") && atoi(getenv("Y2_DTS_THREADS")) == 256 ? 256 : DTS_NT), (size_t)q->classes * sizeof(float), S(s), d, tk,
                            cand_val, cand_cls);
     Y2H_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_collect_sparse_kernel, dim3((unsigned)q->batch), dim3(256), lds2, S(s), q->boxes, cand_val, cand_cls, total, cap,
