@@ -535,6 +535,9 @@ static int autotune_layers(network *net)
                     if (y2h_event_elapsed_ms(e->ev[i], e->ev[i + 1], &m2) != 0) { e->timing = keep_timing; y2_fail("autotune: %s", y2h_last_error()); return -1; }
                     ms = (rep == 0 || m2 < ms) ? m2 : ms;
                 }
+                if (getenv("Y2_AUTOTUNE_LOG"))
+                    fprintf(stderr, "autotune layer %2d %3dx%-3d c%-4d n%-5d k%d%s: %3dx%-3d ks%-2d %.4f ms%s\n", i, l->h, l->w, l->c, l->n, l->size,
+                            c.fuse_maxpool2 ? "+pool" : "", bm[a], bn[a], ks[a], ms, a == 0 ? "  (model)" : "");
                 if (a == 0) ms *= 0.98f;                     /* the model's choice stays unless another wins by 2 % */
                 if (a == 0 || ms < best_ms) { best_ms = ms; best = a; }
             }

@@ -1522,9 +1522,16 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr, int *
         }
         if (force_split > 0) ksplit = force_split <= nk ? force_split : nk;
         const long blocks = tiles * ksplit;
-        long per_cu;
-        if (blocks <= (long)CUS * bpc) per_cu = (blocks + CUS - 1) / CUS;
-        else per_cu = (long)bpc * ((blocks + (long)CUS * bpc - 1) / ((long)CUS * bpc));
+        // work items of the busiest CU.  The grids are persistent (workgroup b walks items b, b + G, ...) and workgroups are
+        // placed round-robin, so the CU that hosts workgroups c, c + 256, ... gets items c, c + 256, c + 512, ...: ceil(items / CUs)
+        // whatever bpc is.  (Round 1's non-persistent grids refilled a CU bpc workgroups at a time, and the model counted the
+        // tail in whole groups of bpc: that over-charged the small tiles on grids of 1.3-2.6 rounds -- autotune logs of yolo 416
+        // b8 / yolo9000 544 b8, profiles/r03_notes.md section 11.)
+        long per_cu = (blocks + CUS - 1) / CUS;
+        if (getenv("Y2_MODEL_R1")) {
+            if (blocks <= (long)CUS * bpc) per_cu = (blocks + CUS - 1) / CUS;
+            else per_cu = (long)bpc * ((blocks + (long)CUS * bpc - 1) / ((long)CUS * bpc));
+        }
         // measured in-tile efficiency relative to the 192x256 tile (yolo.cfg 608x608 b32 sweep,
         // profiles/r01_tile_sweep.txt): bigger wave tiles re-read less LDS per MFMA; the small
         // 64x64 tile wins on short-K 1x1 layers, where prologue/epilogue dominate and four
@@ -1534,7 +1541,7 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr, int *
         else if (v.bm == 128 && v.bn == 128) eff = 0.96;
         else if (v.bm == 256 && v.bn == 128) eff = 0.945;
         else if (v.bm == 64 && v.bn == 64) eff = (d->size == 1) ? 1.0 : 0.90;
-        else if (v.bm == 128 && v.bn == 64) eff = 0.86;
+        else if (v.bm == 128 && v.bn == 64) eff = (d->size == 3 && !getenv("Y2_MODEL_R1")) ? 0.92 : 0.86;     // r3: 0.94-0.95 against the 64x64 tile's 0.90 on grids of 3-5 tiles per CU (52x52 / 68x68 128->256 at batch 8)
         else if (v.bm == 256 && v.bn == 64) eff = 0.82;
         else if (v.bm == 128 && v.bn == 32) eff = (d->size == 1) ? 0.95 : 0.7;
         // in CU cycles: one K-step of a tile = bm*bn*bk*2 flop at 256 flop/clk; ~5 K-steps of fixed cost
