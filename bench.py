@@ -28,6 +28,7 @@ detection-equivalence of the GPU and CPU paths on frames of the timed batch.
 """
 from __future__ import annotations
 
+import gc
 import argparse
 import json
 import os
@@ -560,6 +561,11 @@ def main():
         y2_detect_fetch waits for an event behind step i's D2H copies only, so the next forward is already queued when the
         host blocks.  (A classifier's step is forward + host copy of the class scores: y2_output_enqueue / _fetch.)"""
         res = (None, None)
+        # The harness's own garbage collector stays out of the timed region: the interpreter's first full collection after
+        # `import torch` is a 35-40 ms pause (tools/probes/steps_b1.py: once, ~450 calls into a loop; 0.2 ms per frame of a
+        # 200-step batch-1 run), and what is timed here is the C library, not this script.
+        gc.collect()
+        gc.disable()
         barrier()
         t0 = time.perf_counter()
         forward(0)
@@ -575,6 +581,7 @@ def main():
         res = fetch_results()
         barrier()
         el = time.perf_counter() - t0
+        gc.enable()
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
