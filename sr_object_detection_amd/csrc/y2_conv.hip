@@ -1516,7 +1516,9 @@ static Variant *pick_variant(const y2h_conv *d, int *ksplit_out = nullptr, int *
         int ksplit = 1;
         if (tiles < CUS && nk >= 16) {
             ksplit = (int)((long)CUS * bpc / tiles);
-            if (ksplit > nk / 8) ksplit = nk / 8;
+            // (>= 8 K-steps per range; 1x1 layers >= 4: their ranges are short anyway -- K = 512-1024 is 16-32 steps -- and the
+            // batch-1 autotune logs preferred twice the split on every one of them: yolo 416 b1 device part 0.656 -> 0.648 ms)
+            { const int per = (d->size == 1 && !getenv("Y2_MODEL_R1")) ? 4 : 8; if (ksplit > nk / per) ksplit = nk / per; }
             if (ksplit > 32) ksplit = 32;
             if (ksplit < 1) ksplit = 1;
         }
